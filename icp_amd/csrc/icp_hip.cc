@@ -1,0 +1,716 @@
+// C-ABI implementation (include/icp_hip.h): context, device memory, the registration loop.
+// Host code only; kernels and their launch wrappers live in kernels.hip.
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <dlfcn.h>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "host_common.hh"
+#include "icp_hip.h"
+#include "kernels.hh"
+
+using namespace icp_dev;
+
+namespace
+{
+    thread_local std::string g_error;
+
+    // ---- RCCL, resolved at run time so the library loads (and single-GPU runs work) without it
+    struct Rccl
+    {
+        typedef struct
+        {
+            char internal[128];
+        } UniqueId;
+        typedef void* Comm;
+        int (*GetUniqueId)(UniqueId*) = nullptr;
+        int (*CommInitRank)(Comm*, int, UniqueId, int) = nullptr;
+        int (*AllReduce)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+        int (*CommDestroy)(Comm) = nullptr;
+        const char* (*GetErrorString)(int) = nullptr;
+        void* handle = nullptr;
+        bool tried = false;
+        static constexpr int kDouble = 8; // ncclDouble / ncclFloat64
+        static constexpr int kSum = 0;    // ncclSum
+
+        bool load(std::string& err)
+        {
+            if (handle)
+                return true;
+            if (tried)
+            {
+                err = "RCCL library not available";
+                return false;
+            }
+            tried = true;
+            for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+            {
+                handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (handle)
+                    break;
+            }
+            if (!handle)
+            {
+                err = std::string("cannot load librccl: ") + dlerror();
+                return false;
+            }
+            GetUniqueId = (decltype(GetUniqueId))dlsym(handle, "ncclGetUniqueId");
+            CommInitRank = (decltype(CommInitRank))dlsym(handle, "ncclCommInitRank");
+            AllReduce = (decltype(AllReduce))dlsym(handle, "ncclAllReduce");
+            CommDestroy = (decltype(CommDestroy))dlsym(handle, "ncclCommDestroy");
+            GetErrorString = (decltype(GetErrorString))dlsym(handle, "ncclGetErrorString");
+            if (!GetUniqueId || !CommInitRank || !AllReduce || !CommDestroy)
+            {
+                err = "librccl is missing ncclGetUniqueId/ncclCommInitRank/ncclAllReduce";
+                handle = nullptr;
+                return false;
+            }
+            return true;
+        }
+    } g_rccl;
+
+    template <class T>
+    struct DevBuf
+    {
+        T* p = nullptr;
+        size_t count = 0;
+        hipError_t alloc(size_t n)
+        {
+            release();
+            if (n == 0)
+                return hipSuccess;
+            hipError_t e = hipMalloc((void**)&p, n * sizeof(T));
+            if (e == hipSuccess)
+                count = n;
+            else
+                p = nullptr;
+            return e;
+        }
+        void release()
+        {
+            if (p)
+                (void)hipFree(p);
+            p = nullptr;
+            count = 0;
+        }
+    };
+} // namespace
+
+struct icp_hip_ctx
+{
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // tree replica
+    bool has_tree = false;
+    DevTree tree{};
+    uint32_t height = 0, max_leaf = 0;
+    uint64_t n_tree_points = 0;
+    DevBuf<DevNode> nodes;
+    DevBuf<uint2> leaf_info;
+    DevBuf<float> sx, sy, sz;
+    DevBuf<uint32_t> srow;
+
+    // query shard
+    uint64_t n_local = 0, n_total = 0;
+    bool has_queries = false;
+    DevBuf<float> px, py, pz, yx, yy, yz, aos, dist;
+    DevBuf<uint32_t> row;
+    DevBuf<double> partials, sums;
+    double* h_sums = nullptr; // pinned, 16 doubles
+
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    icp_hip_allreduce_fn allreduce = nullptr;
+    void* allreduce_user = nullptr;
+    Rccl::Comm comm = nullptr;
+    int n_ranks = 1;
+
+    icp_hip_timing timing{};
+};
+
+namespace
+{
+    int fail(icp_hip_ctx* c, int status, const std::string& msg)
+    {
+        if (c)
+            c->err = msg;
+        g_error = msg;
+        return status;
+    }
+    int hip_fail(icp_hip_ctx* c, hipError_t e, const char* what)
+    {
+        return fail(c, e == hipErrorOutOfMemory ? ICP_HIP_ERR_NOMEM : ICP_HIP_ERR_HIP,
+                    std::string(what) + ": " + hipGetErrorString(e));
+    }
+#define HIP_TRY(ctx, expr)                                                                      \
+    do                                                                                          \
+    {                                                                                           \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return hip_fail(ctx, e_, #expr);                                                    \
+    } while (0)
+
+    struct DeviceGuard
+    {
+        int prev = -1;
+        explicit DeviceGuard(int dev)
+        {
+            if (hipGetDevice(&prev) != hipSuccess)
+                prev = -1;
+            if (prev != dev)
+                (void)hipSetDevice(dev);
+            else
+                prev = -1;
+        }
+        ~DeviceGuard()
+        {
+            if (prev >= 0)
+                (void)hipSetDevice(prev);
+        }
+    };
+
+    // time of the kernel(s) between ev0 and ev1, after the stream has been synchronised
+    float elapsed_ms(icp_hip_ctx* c)
+    {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess)
+            ms = 0.f;
+        return ms;
+    }
+
+    // Sum `count` doubles over all shards.  dev -> (RCCL on the stream | host callback) -> host.
+    int reduce_to_host(icp_hip_ctx* c, int count)
+    {
+        if (c->comm)
+        {
+            int rc = g_rccl.AllReduce(c->sums.p, c->sums.p, (size_t)count, Rccl::kDouble,
+                                      Rccl::kSum, c->comm, c->stream);
+            if (rc != 0)
+                return fail(c, ICP_HIP_ERR_COMM,
+                            std::string("ncclAllReduce: ") +
+                                (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"));
+        }
+        HIP_TRY(c, hipMemcpyAsync(c->h_sums, c->sums.p, sizeof(double) * count,
+                                  hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (!c->comm && c->allreduce)
+        {
+            if (c->allreduce(c->h_sums, count, c->allreduce_user) != 0)
+                return fail(c, ICP_HIP_ERR_COMM, "all-reduce callback failed");
+        }
+        return ICP_HIP_OK;
+    }
+
+    NnLaunch make_nn(icp_hip_ctx* c, const float mu[3], bool want_y, bool want_row, bool want_dist,
+                     bool want_cov)
+    {
+        NnLaunch a{};
+        a.tree = c->tree;
+        a.height = c->height;
+        a.max_leaf_count = c->max_leaf;
+        a.px = c->px.p;
+        a.py = c->py.p;
+        a.pz = c->pz.p;
+        a.mu[0] = mu[0];
+        a.mu[1] = mu[1];
+        a.mu[2] = mu[2];
+        a.n = (uint32_t)c->n_local;
+        a.yx = want_y ? c->yx.p : nullptr;
+        a.yy = want_y ? c->yy.p : nullptr;
+        a.yz = want_y ? c->yz.p : nullptr;
+        a.row_out = want_row ? c->row.p : nullptr;
+        a.dist_out = want_dist ? c->dist.p : nullptr;
+        a.partials = want_cov ? c->partials.p : nullptr;
+        a.grid = nn_grid(c->n_local);
+        return a;
+    }
+} // namespace
+
+extern "C"
+{
+    const char* icp_hip_last_global_error(void) { return g_error.c_str(); }
+    const char* icp_hip_last_error(const icp_hip_ctx* ctx)
+    {
+        return ctx ? ctx->err.c_str() : g_error.c_str();
+    }
+
+    int icp_hip_tree_build(const float* xyz_centered, uint64_t n, uint32_t capacity,
+                           icp_flat_tree** out)
+    {
+        if (!out)
+            return fail(nullptr, ICP_HIP_ERR_ARG, "icp_hip_tree_build: out is NULL");
+        icp_host::FlatTreeOwner* owner = nullptr;
+        std::string err;
+        int rc;
+        try
+        {
+            rc = icp_host::build_flat_tree(xyz_centered, n, capacity, &owner, err);
+        }
+        catch (const std::bad_alloc&)
+        {
+            rc = ICP_HIP_ERR_NOMEM;
+            err = "icp_hip_tree_build: out of host memory";
+        }
+        if (rc != ICP_HIP_OK)
+        {
+            *out = nullptr;
+            return fail(nullptr, rc, err);
+        }
+        *out = &owner->view;
+        return ICP_HIP_OK;
+    }
+
+    void icp_hip_tree_free(icp_flat_tree* tree)
+    {
+        // `view` is the first member of FlatTreeOwner
+        delete reinterpret_cast<icp_host::FlatTreeOwner*>(tree);
+    }
+
+    int icp_hip_tree_validate(const icp_flat_tree* tree)
+    {
+        std::string err;
+        int rc;
+        try
+        {
+            rc = icp_host::validate_flat_tree(tree, err);
+        }
+        catch (const std::bad_alloc&)
+        {
+            rc = ICP_HIP_ERR_NOMEM;
+            err = "icp_hip_tree_validate: out of host memory";
+        }
+        return rc == ICP_HIP_OK ? rc : fail(nullptr, rc, err);
+    }
+
+    void icp_hip_mean_host(const float* xyz, uint64_t n, float mu_out[3])
+    {
+        icp_host::mean_host(xyz, n, mu_out);
+    }
+    void icp_hip_center_host(const float* xyz, uint64_t n, const float mu[3], float* out_xyz)
+    {
+        icp_host::center_host(xyz, n, mu, out_xyz);
+    }
+
+    void icp_hip_alignment_host(const float H[9], const float mu_p[3], const float mu_m[3],
+                                float T_out[16])
+    {
+        icp_host::alignment_from_covariance(H, mu_p, mu_m, T_out);
+    }
+
+    int icp_hip_create(icp_hip_ctx** out, int device_id)
+    {
+        if (!out)
+            return fail(nullptr, ICP_HIP_ERR_ARG, "icp_hip_create: out is NULL");
+        *out = nullptr;
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev <= 0)
+            return fail(nullptr, ICP_HIP_ERR_HIP,
+                        std::string("icp_hip_create: no HIP device available (") +
+                            hipGetErrorString(e) + ")");
+        if (device_id < 0)
+        {
+            if (hipGetDevice(&device_id) != hipSuccess)
+                device_id = 0;
+        }
+        if (device_id >= ndev)
+            return fail(nullptr, ICP_HIP_ERR_ARG, "icp_hip_create: device_id out of range");
+        auto* c = new (std::nothrow) icp_hip_ctx();
+        if (!c)
+            return fail(nullptr, ICP_HIP_ERR_NOMEM, "icp_hip_create: out of host memory");
+        c->device = device_id;
+        DeviceGuard g(device_id);
+        auto bail = [&](hipError_t err, const char* what) {
+            int rc = hip_fail(nullptr, err, what);
+            icp_hip_destroy(c);
+            return rc;
+        };
+        if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess)
+            return bail(e, "hipStreamCreate");
+        if ((e = hipEventCreate(&c->ev0)) != hipSuccess)
+            return bail(e, "hipEventCreate");
+        if ((e = hipEventCreate(&c->ev1)) != hipSuccess)
+            return bail(e, "hipEventCreate");
+        if ((e = hipHostMalloc((void**)&c->h_sums, 16 * sizeof(double), hipHostMallocDefault)) !=
+            hipSuccess)
+            return bail(e, "hipHostMalloc");
+        if ((e = c->sums.alloc(16)) != hipSuccess)
+            return bail(e, "hipMalloc(sums)");
+        *out = c;
+        return ICP_HIP_OK;
+    }
+
+    void icp_hip_destroy(icp_hip_ctx* c)
+    {
+        if (!c)
+            return;
+        DeviceGuard g(c->device);
+        if (c->stream)
+            (void)hipStreamSynchronize(c->stream);
+        if (c->comm && g_rccl.CommDestroy)
+            (void)g_rccl.CommDestroy(c->comm);
+        c->nodes.release();
+        c->leaf_info.release();
+        c->sx.release();
+        c->sy.release();
+        c->sz.release();
+        c->srow.release();
+        c->px.release();
+        c->py.release();
+        c->pz.release();
+        c->yx.release();
+        c->yy.release();
+        c->yz.release();
+        c->aos.release();
+        c->dist.release();
+        c->row.release();
+        c->partials.release();
+        c->sums.release();
+        if (c->h_sums)
+            (void)hipHostFree(c->h_sums);
+        if (c->ev0)
+            (void)hipEventDestroy(c->ev0);
+        if (c->ev1)
+            (void)hipEventDestroy(c->ev1);
+        if (c->stream)
+            (void)hipStreamDestroy(c->stream);
+        delete c;
+    }
+
+    int icp_hip_set_tree(icp_hip_ctx* c, const icp_flat_tree* t)
+    {
+        if (!c)
+            return fail(nullptr, ICP_HIP_ERR_ARG, "icp_hip_set_tree: ctx is NULL");
+        {
+            std::string err;
+            int rc = icp_host::validate_flat_tree(t, err);
+            if (rc != ICP_HIP_OK)
+                return fail(c, rc, err);
+        }
+        if ((int)t->height > nn_max_depth_supported())
+            return fail(c, ICP_HIP_ERR_DEPTH,
+                        "icp_hip_set_tree: tree height " + std::to_string(t->height) +
+                            " exceeds the traversal stack (" +
+                            std::to_string(nn_max_depth_supported()) + " levels)");
+        DeviceGuard g(c->device);
+        c->has_tree = false;
+        const size_t nn = t->n_nodes, nl = t->n_leaves, ns = t->n_slots;
+        const size_t slack = 64; // scan_bucket may read one wave past a bucket's last chunk
+
+        // staging for the SoA node arrays, packed into 32-byte records on the device
+        DevBuf<float> f4[4];
+        DevBuf<int32_t> i3[3];
+        DevBuf<uint32_t> nrow;
+        auto cleanup = [&]() {
+            for (auto& b : f4)
+                b.release();
+            for (auto& b : i3)
+                b.release();
+            nrow.release();
+        };
+        hipError_t e = hipSuccess;
+        auto up = [&](auto& buf, const auto* src, size_t n) -> bool {
+            if ((e = buf.alloc(n)) != hipSuccess)
+                return false;
+            if (n == 0)
+                return true;
+            e = hipMemcpyAsync(buf.p, src, n * sizeof(*src), hipMemcpyHostToDevice, c->stream);
+            return e == hipSuccess;
+        };
+        bool ok = c->nodes.alloc(nn ? nn : 1) == hipSuccess;
+        ok = ok && up(f4[0], t->node_cx, nn) && up(f4[1], t->node_cy, nn) &&
+             up(f4[2], t->node_cz, nn) && up(f4[3], t->node_radius, nn) &&
+             up(i3[0], t->node_inside, nn) && up(i3[1], t->node_outside, nn) &&
+             up(i3[2], t->node_parent, nn) && up(nrow, t->node_row, nn);
+        if (ok && nn)
+            ok = (e = launch_pack_nodes(f4[0].p, f4[1].p, f4[2].p, f4[3].p, i3[0].p, i3[1].p,
+                                        i3[2].p, nrow.p, (uint32_t)nn, c->nodes.p, c->stream)) ==
+                 hipSuccess;
+        // leaves {begin,count}
+        std::vector<uint2> li(nl);
+        for (size_t l = 0; l < nl; ++l)
+            li[l] = make_uint2(t->leaf_begin[l], t->leaf_count[l]);
+        ok = ok && up(c->leaf_info, li.data(), nl);
+        // bucket slots (+slack filled with +inf so stray lanes compute inf, never NaN)
+        auto up_slots = [&](DevBuf<float>& buf, const float* src) -> bool {
+            if ((e = buf.alloc(ns + slack)) != hipSuccess)
+                return false;
+            if ((e = hipMemcpyAsync(buf.p, src, ns * sizeof(float), hipMemcpyHostToDevice,
+                                    c->stream)) != hipSuccess)
+                return false;
+            static const std::vector<float> inf(slack, std::numeric_limits<float>::infinity());
+            e = hipMemcpyAsync(buf.p + ns, inf.data(), slack * sizeof(float),
+                               hipMemcpyHostToDevice, c->stream);
+            return e == hipSuccess;
+        };
+        ok = ok && up_slots(c->sx, t->slot_x) && up_slots(c->sy, t->slot_y) &&
+             up_slots(c->sz, t->slot_z) && up(c->srow, t->slot_row, ns);
+        if (ok)
+            ok = (e = hipStreamSynchronize(c->stream)) == hipSuccess;
+        cleanup();
+        if (!ok)
+            return hip_fail(c, e, "icp_hip_set_tree upload");
+
+        c->tree.nodes = c->nodes.p;
+        c->tree.leaf_info = c->leaf_info.p;
+        c->tree.sx = c->sx.p;
+        c->tree.sy = c->sy.p;
+        c->tree.sz = c->sz.p;
+        c->tree.srow = c->srow.p;
+        c->tree.n_slots = (uint32_t)ns;
+        c->tree.n_nodes = (uint32_t)nn;
+        c->tree.root = t->root;
+        c->height = t->height;
+        c->max_leaf = t->max_leaf_count;
+        c->n_tree_points = t->n_points;
+        c->has_tree = true;
+        return ICP_HIP_OK;
+    }
+
+    int icp_hip_set_queries(icp_hip_ctx* c, const float* xyz_aos, uint64_t n_local,
+                            uint64_t n_total)
+    {
+        if (!c)
+            return fail(nullptr, ICP_HIP_ERR_ARG, "icp_hip_set_queries: ctx is NULL");
+        if (n_local > 0 && !xyz_aos)
+            return fail(c, ICP_HIP_ERR_ARG, "icp_hip_set_queries: xyz_aos is NULL");
+        if (n_total < n_local || n_total == 0)
+            return fail(c, ICP_HIP_ERR_ARG, "icp_hip_set_queries: n_total must be >= n_local, > 0");
+        if (n_local >= (1ull << 31))
+            return fail(c, ICP_HIP_ERR_ARG, "icp_hip_set_queries: shard larger than 2^31-1 points");
+        DeviceGuard g(c->device);
+        c->has_queries = false;
+        const size_t n = n_local ? n_local : 1;
+        HIP_TRY(c, c->px.alloc(n));
+        HIP_TRY(c, c->py.alloc(n));
+        HIP_TRY(c, c->pz.alloc(n));
+        HIP_TRY(c, c->yx.alloc(n));
+        HIP_TRY(c, c->yy.alloc(n));
+        HIP_TRY(c, c->yz.alloc(n));
+        HIP_TRY(c, c->aos.alloc(3 * n));
+        HIP_TRY(c, c->row.alloc(n));
+        HIP_TRY(c, c->dist.alloc(n));
+        HIP_TRY(c, c->partials.alloc((size_t)kNnMaxBlocks * kCovSums));
+        if (n_local)
+        {
+            HIP_TRY(c, hipMemcpyAsync(c->aos.p, xyz_aos, 3 * n_local * sizeof(float),
+                                      hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, launch_aos_to_soa(c->aos.p, (uint32_t)n_local, c->px.p, c->py.p, c->pz.p,
+                                         c->stream));
+        }
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->n_local = n_local;
+        c->n_total = n_total;
+        c->has_queries = true;
+        c->timing = icp_hip_timing{};
+        return ICP_HIP_OK;
+    }
+
+    int icp_hip_nn(icp_hip_ctx* c, const float mu_p[3], uint32_t* row_out, float* xyz_out,
+                   float* dist_out, float* kernel_ms)
+    {
+        if (!c || !mu_p)
+            return fail(c, ICP_HIP_ERR_ARG, "icp_hip_nn: NULL argument");
+        if (!c->has_tree || !c->has_queries)
+            return fail(c, ICP_HIP_ERR_ARG, "icp_hip_nn: set_tree and set_queries must come first");
+        DeviceGuard g(c->device);
+        const uint32_t n = (uint32_t)c->n_local;
+        if (kernel_ms)
+            *kernel_ms = 0.f;
+        if (n == 0)
+            return ICP_HIP_OK;
+        NnLaunch a = make_nn(c, mu_p, true, true, true, false);
+        HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+        HIP_TRY(c, launch_nn(a, c->stream));
+        HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+        if (xyz_out)
+            HIP_TRY(c, launch_soa_to_aos(c->yx.p, c->yy.p, c->yz.p, n, c->aos.p, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        const float ms = elapsed_ms(c);
+        c->timing.nn_launches += 1;
+        c->timing.nn_ms += ms;
+        if (kernel_ms)
+            *kernel_ms = ms;
+        if (row_out)
+            HIP_TRY(c, hipMemcpy(row_out, c->row.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        if (dist_out)
+            HIP_TRY(c, hipMemcpy(dist_out, c->dist.p, n * sizeof(float), hipMemcpyDeviceToHost));
+        if (xyz_out)
+            HIP_TRY(c, hipMemcpy(xyz_out, c->aos.p, 3ull * n * sizeof(float),
+                                 hipMemcpyDeviceToHost));
+        return ICP_HIP_OK;
+    }
+
+    int icp_hip_set_allreduce(icp_hip_ctx* c, icp_hip_allreduce_fn fn, void* user)
+    {
+        if (!c)
+            return fail(nullptr, ICP_HIP_ERR_ARG, "icp_hip_set_allreduce: ctx is NULL");
+        c->allreduce = fn;
+        c->allreduce_user = user;
+        return ICP_HIP_OK;
+    }
+
+    int icp_hip_comm_unique_id(void* unique_id_out, size_t size)
+    {
+        if (!unique_id_out || size < sizeof(Rccl::UniqueId))
+            return fail(nullptr, ICP_HIP_ERR_ARG, "icp_hip_comm_unique_id: need a 128-byte buffer");
+        std::string err;
+        if (!g_rccl.load(err))
+            return fail(nullptr, ICP_HIP_ERR_COMM, err);
+        Rccl::UniqueId id;
+        int rc = g_rccl.GetUniqueId(&id);
+        if (rc != 0)
+            return fail(nullptr, ICP_HIP_ERR_COMM, "ncclGetUniqueId failed");
+        std::memcpy(unique_id_out, &id, sizeof id);
+        return ICP_HIP_OK;
+    }
+
+    int icp_hip_comm_init_rank(icp_hip_ctx* c, int n_ranks, int rank, const void* unique_id,
+                               size_t size)
+    {
+        if (!c || !unique_id || size < sizeof(Rccl::UniqueId) || n_ranks < 1 || rank < 0 ||
+            rank >= n_ranks)
+            return fail(c, ICP_HIP_ERR_ARG, "icp_hip_comm_init_rank: bad argument");
+        std::string err;
+        if (!g_rccl.load(err))
+            return fail(c, ICP_HIP_ERR_COMM, err);
+        DeviceGuard g(c->device);
+        Rccl::UniqueId id;
+        std::memcpy(&id, unique_id, sizeof id);
+        if (c->comm)
+        {
+            (void)g_rccl.CommDestroy(c->comm);
+            c->comm = nullptr;
+        }
+        int rc = g_rccl.CommInitRank(&c->comm, n_ranks, id, rank);
+        if (rc != 0)
+        {
+            c->comm = nullptr;
+            return fail(c, ICP_HIP_ERR_COMM,
+                        std::string("ncclCommInitRank: ") +
+                            (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"));
+        }
+        c->n_ranks = n_ranks;
+        return ICP_HIP_OK;
+    }
+
+    int icp_hip_run(icp_hip_ctx* c, const float mu_m[3], uint64_t max_iters, float threshold,
+                    float T_out[16], uint64_t* iters_done, float* final_error,
+                    icp_hip_progress_fn progress, void* user)
+    {
+        if (!c || !mu_m || !T_out)
+            return fail(c, ICP_HIP_ERR_ARG, "icp_hip_run: NULL argument");
+        if (!c->has_tree || !c->has_queries)
+            return fail(c, ICP_HIP_ERR_ARG, "icp_hip_run: set_tree and set_queries must come first");
+        DeviceGuard g(c->device);
+        const auto t_begin = std::chrono::steady_clock::now();
+        const uint32_t n = (uint32_t)c->n_local;
+        const uint32_t g_nn = nn_grid(n), g_st = stream_grid(n);
+        const double n_total = (double)c->n_total;
+
+        float T[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}; // icp.cc:101
+        float error = std::numeric_limits<float>::infinity();           // icp.cc:104
+        uint64_t it = 0;
+        int rc;
+
+        // first mean(p) (icp.cc:114); later iterations get it from the apply pass
+        float mu_p[3] = {0, 0, 0};
+        if (max_iters > 0 && error > threshold)
+        {
+            HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+            HIP_TRY(c, launch_sum_points(c->px.p, c->py.p, c->pz.p, n, g_st, c->partials.p,
+                                         c->stream));
+            HIP_TRY(c, launch_reduce_partials(c->partials.p, g_st, kApplySums, c->sums.p,
+                                              c->stream));
+            HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+            if ((rc = reduce_to_host(c, kApplySums)) != ICP_HIP_OK)
+                return rc;
+            c->timing.reduce_ms += elapsed_ms(c);
+            for (int k = 0; k < 3; ++k)
+                mu_p[k] = (float)(c->h_sums[1 + k] / n_total);
+        }
+
+        for (; it < max_iters && error > threshold; ++it) // icp.cc:110
+        {
+            // y = tree.closest(p - mu_p); H = sum (p - mu_p) (x) y      icp.cc:115-117, :32-33
+            NnLaunch a = make_nn(c, mu_p, true, false, false, true);
+            HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+            HIP_TRY(c, launch_nn(a, c->stream));
+            HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+            HIP_TRY(c, launch_reduce_partials(c->partials.p, g_nn, kCovSums, c->sums.p, c->stream));
+            if ((rc = reduce_to_host(c, kCovSums)) != ICP_HIP_OK)
+                return rc;
+            c->timing.nn_ms += elapsed_ms(c);
+            c->timing.nn_launches += 1;
+
+            float H[9], Tn[16], Tt[16];
+            for (int k = 0; k < 9; ++k)
+                H[k] = (float)c->h_sums[k];
+            icp_host::alignment_from_covariance(H, mu_p, mu_m, Tn); // icp.cc:119
+            icp_host::matmul4(Tn, T, Tt);                           // icp.cc:121
+            std::memcpy(T, Tt, sizeof T);
+
+            // p <- Tn p ; error ; next centroid                      icp.cc:122-123
+            Mat34 M;
+            std::memcpy(M.m, Tn, sizeof M.m);
+            HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+            HIP_TRY(c, launch_apply_error(c->px.p, c->py.p, c->pz.p, c->yx.p, c->yy.p, c->yz.p, M,
+                                          mu_m, n, g_st, c->partials.p, c->stream));
+            HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+            HIP_TRY(c, launch_reduce_partials(c->partials.p, g_st, kApplySums, c->sums.p,
+                                              c->stream));
+            if ((rc = reduce_to_host(c, kApplySums)) != ICP_HIP_OK)
+                return rc;
+            c->timing.apply_ms += elapsed_ms(c);
+            error = (float)c->h_sums[0];
+            for (int k = 0; k < 3; ++k)
+                mu_p[k] = (float)(c->h_sums[1 + k] / n_total);
+            if (progress)
+                progress(it + 1, max_iters, error, user);
+        }
+        std::memcpy(T_out, T, sizeof T);
+        if (iters_done)
+            *iters_done = it;
+        if (final_error)
+            *final_error = error;
+        c->timing.host_ms +=
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin)
+                .count();
+        return ICP_HIP_OK;
+    }
+
+    int icp_hip_get_points(icp_hip_ctx* c, float* xyz_aos)
+    {
+        if (!c || !c->has_queries)
+            return fail(c, ICP_HIP_ERR_ARG, "icp_hip_get_points: no query shard set");
+        if (c->n_local == 0)
+            return ICP_HIP_OK;
+        if (!xyz_aos)
+            return fail(c, ICP_HIP_ERR_ARG, "icp_hip_get_points: xyz_aos is NULL");
+        DeviceGuard g(c->device);
+        const uint32_t n = (uint32_t)c->n_local;
+        HIP_TRY(c, launch_soa_to_aos(c->px.p, c->py.p, c->pz.p, n, c->aos.p, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(xyz_aos, c->aos.p, 3ull * n * sizeof(float),
+                                  hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return ICP_HIP_OK;
+    }
+
+    int icp_hip_get_timing(icp_hip_ctx* c, icp_hip_timing* out)
+    {
+        if (!c || !out)
+            return fail(c, ICP_HIP_ERR_ARG, "icp_hip_get_timing: NULL argument");
+        *out = c->timing;
+        return ICP_HIP_OK;
+    }
+}

@@ -1,0 +1,77 @@
+// Device-side data layout and launch wrappers (see kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace icp_dev
+{
+    // One internal node = one 32-byte record = two 16-byte loads from one 32-byte aligned segment:
+    // a lane visiting a node needs all eight words, so the node side of the tree is packed per
+    // node; the bucket side, which 64 lanes sweep together, is SoA (sx/sy/sz).
+    struct __attribute__((aligned(32))) DevNode
+    {
+        float cx, cy, cz, r;
+        int32_t inside, outside, parent; // child codes: >= 0 internal index, < 0 ~leaf
+        uint32_t row;
+    };
+
+    struct DevTree
+    {
+        const DevNode* nodes;
+        const uint2* leaf_info; // {first slot, count}
+        const float* sx;        // bucket slots (+64 slots of slack behind n_slots)
+        const float* sy;
+        const float* sz;
+        const uint32_t* srow;
+        uint32_t n_slots;
+        uint32_t n_nodes;
+        int32_t root;
+    };
+
+    struct Mat34
+    {
+        float m[12]; // rows 0..2 of the row-major 4x4
+    };
+
+    constexpr int kCovSums = 9;   // sum q (x) y, row = P coordinate, col = Y coordinate
+    constexpr int kApplySums = 4; // error, sum x', sum y', sum z'
+    constexpr uint32_t kNnMaxBlocks = 256 * 8;
+    constexpr uint32_t kStreamMaxBlocks = 256 * 8;
+
+    struct NnLaunch
+    {
+        DevTree tree;
+        uint32_t height;
+        uint32_t max_leaf_count;
+        const float *px, *py, *pz;
+        float mu[3];
+        uint32_t n;
+        float *yx, *yy, *yz; // may be null together
+        uint32_t* row_out;   // may be null
+        float* dist_out;     // may be null
+        double* partials;    // [grid][kCovSums] or null
+        uint32_t grid;
+    };
+
+    int nn_max_depth_supported();
+    uint32_t nn_grid(uint64_t n);
+    uint32_t stream_grid(uint64_t n);
+
+    hipError_t launch_nn(const NnLaunch& a, hipStream_t s);
+    hipError_t launch_apply_error(float* px, float* py, float* pz, const float* yx, const float* yy,
+                                  const float* yz, const Mat34& T, const float mu_m[3], uint32_t n,
+                                  uint32_t grid, double* partials, hipStream_t s);
+    hipError_t launch_sum_points(const float* px, const float* py, const float* pz, uint32_t n,
+                                 uint32_t grid, double* partials, hipStream_t s);
+    hipError_t launch_reduce_partials(const double* partials, uint32_t nblocks, int K, double* out,
+                                      hipStream_t s);
+    hipError_t launch_aos_to_soa(const float* aos, uint32_t n, float* x, float* y, float* z,
+                                 hipStream_t s);
+    hipError_t launch_soa_to_aos(const float* x, const float* y, const float* z, uint32_t n,
+                                 float* aos, hipStream_t s);
+    hipError_t launch_pack_nodes(const float* cx, const float* cy, const float* cz, const float* r,
+                                 const int32_t* inside, const int32_t* outside,
+                                 const int32_t* parent, const uint32_t* row, uint32_t n,
+                                 DevNode* out, hipStream_t s);
+} // namespace icp_dev

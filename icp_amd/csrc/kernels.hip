@@ -1,0 +1,621 @@
+// gfx950 (MI355X, CDNA4) kernels of the registration path.  wave = 64 lanes everywhere.
+//
+//   nn_cov_kernel        VPTree::search / closest (libcpu/libcpu/vp-tree.cc:125-187) for one shard
+//                        of queries + the nine cross-covariance sums of find_covariance
+//                        (libcpu/libcpu/point-3d.cc:212-236) fused behind it.
+//                        Replaces closest_kernel (libgpu/libgpu/vp-tree.cu:181-261), subtract_rowwise
+//                        (matrix.cu:243-270), product_kernel + sum_colwise (matrix.cu:369-421).
+//   apply_error_kernel   apply_alignment (libcpu/libcpu/icp.cc:62-79) + compute_error (:81-95) + the
+//                        next iteration's centroid sums.  Replaces apply_alignment_kernel /
+//                        compute_error_kernel (libgpu/libgpu/icp.cu:64-125) and divide/block_sum.
+//   sum_points_kernel    centroid sums of the untouched cloud (first iteration's mean, icp.cc:114).
+//   reduce_partials      fixed-order second stage of every reduction (deterministic results).
+//   aos_to_soa / soa_to_aos   Point3D <-> device SoA.
+//
+// Bit-exactness: every distance is sqrt(((dx*dx)+(dy*dy))+(dz*dz)) in fp32 with separately
+// rounded multiplies and adds (__fmul_rn/__fadd_rn/__fsub_rn never contract; the file is also
+// built with -ffp-contract=off) and a correctly rounded sqrtf, exactly as the reference's x86-64
+// SSE2 build evaluates point-3d.cc:136-143.  Comparisons are made on the sqrt'ed values like
+// vp-tree.cc:132-173 (two different squared distances can share one sqrt).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.hh"
+
+namespace icp_dev
+{
+    constexpr int kWave = 64;
+    constexpr int kBlock = 256;
+    constexpr int kWavesPerBlock = kBlock / kWave;
+
+    __device__ __forceinline__ float sq_dist(float ax, float ay, float az, float bx, float by,
+                                             float bz)
+    {
+        const float dx = __fsub_rn(ax, bx);
+        const float dy = __fsub_rn(ay, by);
+        const float dz = __fsub_rn(az, bz);
+        return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+    }
+
+    __device__ __forceinline__ float readlane_f(float v, int l)
+    {
+        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+    }
+    __device__ __forceinline__ uint32_t readlane_u(uint32_t v, int l)
+    {
+        return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+    }
+
+    // Minimum over the 64 lanes of a NON-NEGATIVE float (incl. +inf): such floats order like their
+    // bit patterns, so the reduction runs on ints through DPP row shifts and row broadcasts
+    // (no LDS traffic).  Result is wave-uniform.
+    __device__ __forceinline__ float wave_min_nonneg(float v)
+    {
+        int x = __float_as_int(v);
+        x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x111, 0xf, 0xf, false)); // row_shr:1
+        x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x112, 0xf, 0xf, false)); // row_shr:2
+        x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x114, 0xf, 0xf, false)); // row_shr:4
+        x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x118, 0xf, 0xf, false)); // row_shr:8
+        x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x142, 0xa, 0xf, false)); // row_bcast:15
+        x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x143, 0xc, 0xf, false)); // row_bcast:31
+        return __int_as_float(__builtin_amdgcn_readlane(x, 63));
+    }
+
+    // Largest squared distance whose correctly rounded fp32 sqrt still equals r = sqrtf(s_min).
+    // sqrt(s) rounds to r  <=>  sqrt(s) < (r + next(r))/2 =: m  <=>  s < m*m ; m has <= 25
+    // significant bits so m*m is exact in fp64 and is never itself an fp32 value.
+    __device__ __forceinline__ float sq_ceiling_for_root(float r)
+    {
+        const float r_up = __uint_as_float(__float_as_uint(r) + 1u);
+        const double m = 0.5 * ((double)r + (double)r_up);
+        const double m2 = m * m;
+        float f = (float)m2; // round to nearest ...
+        if ((double)f > m2)  // ... then step down to the largest float below m2
+            f = __uint_as_float(__float_as_uint(f) - 1u);
+        return f;
+    }
+
+    // Wave-cooperative scan of one leaf bucket for ONE query (all arguments wave-uniform).
+    // Reference rule (vp-tree.cc:131-143): best = first slot i minimising sqrt(d2_i) under strict <.
+    // Equivalent evaluation: r = sqrt(min d2); winner = first slot whose d2 <= ceiling(r).
+    template <int NCH>
+    __device__ __forceinline__ void scan_bucket(const DevTree& t, float bx, float by, float bz,
+                                                uint32_t beg, uint32_t cnt, int lane, float& r_out,
+                                                uint32_t& win_out)
+    {
+        const float kInf = __int_as_float(0x7f800000);
+        float smin = kInf;
+        uint32_t win = beg; // a NaN-poisoned bucket keeps slot 0, like the reference's scan
+        if constexpr (NCH > 0)
+        {
+            float s[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+            {
+                s[c] = kInf;
+                if ((uint32_t)(c * kWave) < cnt) // wave-uniform
+                {
+                    const uint32_t j = c * kWave + lane;
+                    // buckets are over-allocated by one wave of slots, so this never leaves the array
+                    const float x = t.sx[beg + j], y = t.sy[beg + j], z = t.sz[beg + j];
+                    const float d2 = sq_dist(bx, by, bz, x, y, z);
+                    s[c] = (j < cnt) ? d2 : kInf;
+                    smin = fminf(smin, s[c]);
+                }
+            }
+            const float m = wave_min_nonneg(smin);
+            const float r = sqrtf(m);
+            const float hi = sq_ceiling_for_root(r);
+            bool found = false;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+            {
+                if (!found && (uint32_t)(c * kWave) < cnt)
+                {
+                    const uint64_t hit = __ballot(s[c] <= hi);
+                    if (hit)
+                    {
+                        win = beg + c * kWave + (uint32_t)__builtin_ctzll(hit);
+                        found = true;
+                    }
+                }
+            }
+            r_out = r;
+        }
+        else
+        {
+            for (uint32_t c0 = 0; c0 < cnt; c0 += kWave)
+            {
+                const uint32_t j = c0 + lane;
+                const float x = t.sx[beg + j], y = t.sy[beg + j], z = t.sz[beg + j];
+                const float d2 = sq_dist(bx, by, bz, x, y, z);
+                smin = fminf(smin, (j < cnt) ? d2 : kInf);
+            }
+            const float m = wave_min_nonneg(smin);
+            const float r = sqrtf(m);
+            const float hi = sq_ceiling_for_root(r);
+            for (uint32_t c0 = 0; c0 < cnt; c0 += kWave)
+            {
+                const uint32_t j = c0 + lane;
+                const float x = t.sx[beg + j], y = t.sy[beg + j], z = t.sz[beg + j];
+                const float d2 = sq_dist(bx, by, bz, x, y, z);
+                const uint64_t hit = __ballot((j < cnt) && (d2 <= hi));
+                if (hit)
+                {
+                    win = beg + c0 + (uint32_t)__builtin_ctzll(hit);
+                    break;
+                }
+            }
+            r_out = r;
+        }
+        win_out = win;
+    }
+
+    __device__ __forceinline__ double wave_sum_f64(double v)
+    {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+            v += __shfl_down(v, off, kWave);
+        return v; // lane 0 holds the sum
+    }
+
+    // Block-level fixed-order sum of K per-lane doubles -> partials[blockIdx.x * K + k].
+    template <int K>
+    __device__ __forceinline__ void block_store_partials(const double (&acc)[K], double* red,
+                                                         double* partials)
+    {
+        const int lane = threadIdx.x & (kWave - 1);
+        const int w = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+        {
+            const double s = wave_sum_f64(acc[k]);
+            if (lane == 0)
+                red[w * K + k] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < K)
+        {
+            double s = 0.0;
+#pragma unroll
+            for (int ww = 0; ww < kWavesPerBlock; ++ww)
+                s += red[ww * K + threadIdx.x];
+            partials[(size_t)blockIdx.x * K + threadIdx.x] = s;
+        }
+    }
+
+    enum : int
+    {
+        kDescend = 0, // arriving at `node` from its parent
+        kReturn = 1,  // arriving at `node` from child `prev`, (rd, rid) = that child's answer
+        kWaitLeaf = 2,
+        kDone = 3
+    };
+
+    // One lane per query; the recursion of VPTree::search is unrolled into a per-lane state
+    // machine.  Parent links replace a node stack; the only per-level state is the near side's
+    // answer while the far side is searched, kept in LDS as [level][lane] (bank == lane, so it is
+    // conflict free at any mix of depths).  Leaf buckets are scanned by the whole wave for one
+    // query at a time with coalesced 256-byte loads.
+    template <int MAXD, int NCH>
+    __global__ void __launch_bounds__(kBlock)
+        nn_cov_kernel(DevTree t, const float* __restrict__ px, const float* __restrict__ py,
+                      const float* __restrict__ pz, float mux, float muy, float muz, uint32_t n,
+                      float* __restrict__ yx, float* __restrict__ yy, float* __restrict__ yz,
+                      uint32_t* __restrict__ row_out, float* __restrict__ dist_out,
+                      double* __restrict__ partials)
+    {
+        __shared__ float s_near_d[kWavesPerBlock * MAXD * kWave];
+        __shared__ uint32_t s_near_i[kWavesPerBlock * MAXD * kWave];
+        __shared__ double s_red[kWavesPerBlock * kCovSums];
+
+        const int lane = threadIdx.x & (kWave - 1);
+        const int w = threadIdx.x >> 6;
+        float* near_d = s_near_d + w * MAXD * kWave + lane;
+        uint32_t* near_i = s_near_i + w * MAXD * kWave + lane;
+
+        double acc[kCovSums];
+#pragma unroll
+        for (int k = 0; k < kCovSums; ++k)
+            acc[k] = 0.0;
+
+        const uint32_t wave_stride = gridDim.x * kWavesPerBlock * kWave;
+        for (uint32_t base = (blockIdx.x * kWavesPerBlock + w) * kWave; base < n;
+             base += wave_stride)
+        {
+            const uint32_t i = base + lane;
+            const bool valid = i < n;
+            float qx = 0.f, qy = 0.f, qz = 0.f;
+            if (valid)
+            {
+                // p_centered = p - mu_p (point-3d.cc:202-206)
+                qx = __fsub_rn(px[i], mux);
+                qy = __fsub_rn(py[i], muy);
+                qz = __fsub_rn(pz[i], muz);
+            }
+            int node = t.root, prev = 0, level = 0;
+            int mode = kDescend;
+            float rd = 0.f;
+            uint32_t rid = 0;
+            uint32_t lbeg = 0, lcnt = 0;
+            if (!valid)
+                mode = kDone;
+            else if (t.root < 0)
+            {
+                const uint2 li = t.leaf_info[~t.root];
+                lbeg = li.x;
+                lcnt = li.y;
+                prev = t.root;
+                node = -1;
+                mode = kWaitLeaf;
+            }
+
+            for (;;)
+            {
+                // ---- node phase: step every lane until it waits on a bucket or is done ----
+                while (__ballot(mode <= kReturn) != 0ull)
+                {
+                    if (mode <= kReturn)
+                    {
+                        const DevNode N = t.nodes[node];
+                        const float d = sqrtf(sq_dist(qx, qy, qz, N.cx, N.cy, N.cz)); // :147
+                        const bool in_near = d < N.r;                                // :148
+                        const int nearc = in_near ? N.inside : N.outside;
+                        const int farc = in_near ? N.outside : N.inside;
+                        int go = nearc;
+                        bool down = true;
+                        if (mode == kReturn)
+                        {
+                            bool up;
+                            if (prev == nearc)
+                            {
+                                // back from the near side (:152)
+                                if (rd < fabsf(__fsub_rn(N.r, d)))
+                                    up = true;
+                                else
+                                {
+                                    near_d[level * kWave] = rd;
+                                    near_i[level * kWave] = rid;
+                                    go = farc; // :160
+                                    up = false;
+                                }
+                            }
+                            else
+                            {
+                                // back from the far side (:163): far wins only if strictly closer
+                                const float nd = near_d[level * kWave];
+                                const uint32_t ni = near_i[level * kWave];
+                                if (!(rd < nd))
+                                {
+                                    rd = nd;
+                                    rid = ni;
+                                }
+                                up = true;
+                            }
+                            down = !up;
+                            if (up)
+                            {
+                                if (d < rd) // :154 / :165 / :171 the centre wins only if strictly closer
+                                {
+                                    rd = d;
+                                    rid = t.n_slots + (uint32_t)node;
+                                }
+                                prev = node;
+                                node = N.parent;
+                                level -= 1;
+                                mode = node < 0 ? kDone : kReturn;
+                            }
+                        }
+                        if (down)
+                        {
+                            if (go >= 0)
+                            {
+                                node = go;
+                                level += 1;
+                                mode = kDescend;
+                            }
+                            else
+                            {
+                                const uint2 li = t.leaf_info[~go];
+                                lbeg = li.x;
+                                lcnt = li.y;
+                                prev = go;
+                                mode = kWaitLeaf;
+                            }
+                        }
+                    }
+                }
+                // ---- leaf phase: the wave serves its waiting lanes one bucket at a time ----
+                uint64_t pend = __ballot(mode == kWaitLeaf);
+                if (pend == 0ull)
+                    break;
+                while (pend)
+                {
+                    const int l = (int)__builtin_ctzll(pend);
+                    pend &= pend - 1;
+                    const float bx = readlane_f(qx, l), by = readlane_f(qy, l),
+                                bz = readlane_f(qz, l);
+                    const uint32_t beg = readlane_u(lbeg, l), cnt = readlane_u(lcnt, l);
+                    float r;
+                    uint32_t win;
+                    scan_bucket<NCH>(t, bx, by, bz, beg, cnt, lane, r, win);
+                    if (lane == l)
+                    {
+                        rd = r;
+                        rid = win;
+                        mode = node < 0 ? kDone : kReturn;
+                    }
+                }
+            }
+
+            if (valid)
+            {
+                float ox, oy, oz;
+                uint32_t row;
+                if (rid < t.n_slots)
+                {
+                    ox = t.sx[rid];
+                    oy = t.sy[rid];
+                    oz = t.sz[rid];
+                    row = t.srow[rid];
+                }
+                else
+                {
+                    const DevNode N = t.nodes[rid - t.n_slots];
+                    ox = N.cx;
+                    oy = N.cy;
+                    oz = N.cz;
+                    row = N.row;
+                }
+                if (yx)
+                {
+                    yx[i] = ox;
+                    yy[i] = oy;
+                    yz[i] = oz;
+                }
+                if (row_out)
+                    row_out[i] = row;
+                if (dist_out)
+                    dist_out[i] = rd;
+                // fp32 products as find_covariance forms them (point-3d.cc:220-231), summed in fp64
+                acc[0] += (double)__fmul_rn(qx, ox);
+                acc[1] += (double)__fmul_rn(qx, oy);
+                acc[2] += (double)__fmul_rn(qx, oz);
+                acc[3] += (double)__fmul_rn(qy, ox);
+                acc[4] += (double)__fmul_rn(qy, oy);
+                acc[5] += (double)__fmul_rn(qy, oz);
+                acc[6] += (double)__fmul_rn(qz, ox);
+                acc[7] += (double)__fmul_rn(qz, oy);
+                acc[8] += (double)__fmul_rn(qz, oz);
+            }
+        }
+        if (partials)
+            block_store_partials<kCovSums>(acc, s_red, partials);
+    }
+
+    // p <- T p (icp.cc:66-74, left-to-right adds, no FMA); error terms (icp.cc:88-91);
+    // sums: [0] error, [1..3] moved-point coordinates (next mean).
+    __global__ void __launch_bounds__(kBlock)
+        apply_error_kernel(float* __restrict__ px, float* __restrict__ py, float* __restrict__ pz,
+                           const float* __restrict__ yx, const float* __restrict__ yy,
+                           const float* __restrict__ yz, Mat34 T, float mmx, float mmy, float mmz,
+                           uint32_t n, double* __restrict__ partials)
+    {
+        __shared__ double s_red[kWavesPerBlock * kApplySums];
+        double acc[kApplySums] = {0.0, 0.0, 0.0, 0.0};
+        for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+        {
+            const float x = px[i], y = py[i], z = pz[i];
+            const float nx = __fadd_rn(
+                __fadd_rn(__fadd_rn(__fmul_rn(x, T.m[0]), __fmul_rn(y, T.m[1])), __fmul_rn(z, T.m[2])),
+                T.m[3]);
+            const float ny = __fadd_rn(
+                __fadd_rn(__fadd_rn(__fmul_rn(x, T.m[4]), __fmul_rn(y, T.m[5])), __fmul_rn(z, T.m[6])),
+                T.m[7]);
+            const float nz = __fadd_rn(
+                __fadd_rn(__fadd_rn(__fmul_rn(x, T.m[8]), __fmul_rn(y, T.m[9])), __fmul_rn(z, T.m[10])),
+                T.m[11]);
+            px[i] = nx;
+            py[i] = ny;
+            pz[i] = nz;
+            const float ex = __fsub_rn(__fadd_rn(yx[i], mmx), nx);
+            const float ey = __fsub_rn(__fadd_rn(yy[i], mmy), ny);
+            const float ez = __fsub_rn(__fadd_rn(yz[i], mmz), nz);
+            const float e =
+                __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(ez, ez));
+            acc[0] += (double)e;
+            acc[1] += (double)nx;
+            acc[2] += (double)ny;
+            acc[3] += (double)nz;
+        }
+        block_store_partials<kApplySums>(acc, s_red, partials);
+    }
+
+    __global__ void __launch_bounds__(kBlock)
+        sum_points_kernel(const float* __restrict__ px, const float* __restrict__ py,
+                          const float* __restrict__ pz, uint32_t n, double* __restrict__ partials)
+    {
+        __shared__ double s_red[kWavesPerBlock * kApplySums];
+        double acc[kApplySums] = {0.0, 0.0, 0.0, 0.0};
+        for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+        {
+            acc[1] += (double)px[i];
+            acc[2] += (double)py[i];
+            acc[3] += (double)pz[i];
+        }
+        block_store_partials<kApplySums>(acc, s_red, partials);
+    }
+
+    // out[k] = sum over blocks of partials[b*K + k], in a fixed order (bitwise reproducible).
+    __global__ void __launch_bounds__(kBlock)
+        reduce_partials_kernel(const double* __restrict__ partials, uint32_t nblocks, int K,
+                               double* __restrict__ out)
+    {
+        __shared__ double s[kBlock];
+        for (int k = 0; k < K; ++k)
+        {
+            double v = 0.0;
+            for (uint32_t b = threadIdx.x; b < nblocks; b += kBlock)
+                v += partials[(size_t)b * K + k];
+            s[threadIdx.x] = v;
+            __syncthreads();
+            for (int off = kBlock / 2; off > 0; off >>= 1)
+            {
+                if ((int)threadIdx.x < off)
+                    s[threadIdx.x] += s[threadIdx.x + off];
+                __syncthreads();
+            }
+            if (threadIdx.x == 0)
+                out[k] = s[0];
+            __syncthreads();
+        }
+    }
+
+    __global__ void __launch_bounds__(kBlock)
+        aos_to_soa_kernel(const float* __restrict__ aos, uint32_t n, float* __restrict__ x,
+                          float* __restrict__ y, float* __restrict__ z)
+    {
+        for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+        {
+            x[i] = aos[3 * (size_t)i];
+            y[i] = aos[3 * (size_t)i + 1];
+            z[i] = aos[3 * (size_t)i + 2];
+        }
+    }
+
+    __global__ void __launch_bounds__(kBlock)
+        soa_to_aos_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                          const float* __restrict__ z, uint32_t n, float* __restrict__ aos)
+    {
+        for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+        {
+            aos[3 * (size_t)i] = x[i];
+            aos[3 * (size_t)i + 1] = y[i];
+            aos[3 * (size_t)i + 2] = z[i];
+        }
+    }
+
+    // SoA host tree arrays -> packed 32-byte node records.
+    __global__ void __launch_bounds__(kBlock)
+        pack_nodes_kernel(const float* cx, const float* cy, const float* cz, const float* r,
+                          const int32_t* inside, const int32_t* outside, const int32_t* parent,
+                          const uint32_t* row, uint32_t n, DevNode* __restrict__ out)
+    {
+        for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+        {
+            DevNode N;
+            N.cx = cx[i];
+            N.cy = cy[i];
+            N.cz = cz[i];
+            N.r = r[i];
+            N.inside = inside[i];
+            N.outside = outside[i];
+            N.parent = parent[i];
+            N.row = row[i];
+            out[i] = N;
+        }
+    }
+
+    // ------------------------------------------------------------------------------------
+    // launch wrappers (plain C++ so the C-ABI translation unit needs no kernel syntax)
+    // ------------------------------------------------------------------------------------
+    static inline uint32_t grid_for(uint64_t n, uint32_t cap_blocks)
+    {
+        uint64_t b = (n + kBlock - 1) / kBlock;
+        if (b < 1)
+            b = 1;
+        return (uint32_t)(b < cap_blocks ? b : cap_blocks);
+    }
+
+    template <int MAXD>
+    static hipError_t launch_nn_d(const NnLaunch& a, hipStream_t s)
+    {
+        const dim3 g(a.grid), b(kBlock);
+#define ICP_NN_GO(NCH)                                                                          \
+    hipLaunchKernelGGL((nn_cov_kernel<MAXD, NCH>), g, b, 0, s, a.tree, a.px, a.py, a.pz, a.mu[0], \
+                       a.mu[1], a.mu[2], a.n, a.yx, a.yy, a.yz, a.row_out, a.dist_out, a.partials)
+        if (a.max_leaf_count <= 64)
+            ICP_NN_GO(1);
+        else if (a.max_leaf_count <= 128)
+            ICP_NN_GO(2);
+        else if (a.max_leaf_count <= 256)
+            ICP_NN_GO(4);
+        else
+            ICP_NN_GO(0);
+#undef ICP_NN_GO
+        return hipGetLastError();
+    }
+
+    int nn_max_depth_supported() { return 64; }
+
+    uint32_t nn_grid(uint64_t n) { return grid_for(n, kNnMaxBlocks); }
+    uint32_t stream_grid(uint64_t n) { return grid_for(n, kStreamMaxBlocks); }
+
+    hipError_t launch_nn(const NnLaunch& a, hipStream_t s)
+    {
+        // the LDS stack is indexed by the depth of an internal node: 0 .. height-1
+        if (a.height <= 12)
+            return launch_nn_d<12>(a, s);
+        if (a.height <= 20)
+            return launch_nn_d<20>(a, s);
+        if (a.height <= 32)
+            return launch_nn_d<32>(a, s);
+        if (a.height <= 64)
+            return launch_nn_d<64>(a, s);
+        return hipErrorInvalidValue;
+    }
+
+    hipError_t launch_apply_error(float* px, float* py, float* pz, const float* yx, const float* yy,
+                                  const float* yz, const Mat34& T, const float mu_m[3], uint32_t n,
+                                  uint32_t grid, double* partials, hipStream_t s)
+    {
+        hipLaunchKernelGGL(apply_error_kernel, dim3(grid), dim3(kBlock), 0, s, px, py, pz, yx, yy,
+                           yz, T, mu_m[0], mu_m[1], mu_m[2], n, partials);
+        return hipGetLastError();
+    }
+
+    hipError_t launch_sum_points(const float* px, const float* py, const float* pz, uint32_t n,
+                                 uint32_t grid, double* partials, hipStream_t s)
+    {
+        hipLaunchKernelGGL(sum_points_kernel, dim3(grid), dim3(kBlock), 0, s, px, py, pz, n,
+                           partials);
+        return hipGetLastError();
+    }
+
+    hipError_t launch_reduce_partials(const double* partials, uint32_t nblocks, int K, double* out,
+                                      hipStream_t s)
+    {
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kBlock), 0, s, partials, nblocks,
+                           K, out);
+        return hipGetLastError();
+    }
+
+    hipError_t launch_aos_to_soa(const float* aos, uint32_t n, float* x, float* y, float* z,
+                                 hipStream_t s)
+    {
+        hipLaunchKernelGGL(aos_to_soa_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, s, aos, n, x,
+                           y, z);
+        return hipGetLastError();
+    }
+
+    hipError_t launch_soa_to_aos(const float* x, const float* y, const float* z, uint32_t n,
+                                 float* aos, hipStream_t s)
+    {
+        hipLaunchKernelGGL(soa_to_aos_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, s, x, y, z, n,
+                           aos);
+        return hipGetLastError();
+    }
+
+    hipError_t launch_pack_nodes(const float* cx, const float* cy, const float* cz, const float* r,
+                                 const int32_t* inside, const int32_t* outside,
+                                 const int32_t* parent, const uint32_t* row, uint32_t n,
+                                 DevNode* out, hipStream_t s)
+    {
+        if (n == 0)
+            return hipSuccess;
+        hipLaunchKernelGGL(pack_nodes_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, s, cx, cy, cz,
+                           r, inside, outside, parent, row, n, out);
+        return hipGetLastError();
+    }
+} // namespace icp_dev

@@ -1,0 +1,189 @@
+/* icp_hip.h -- C ABI of the MI355X (gfx950) registration backend.
+ *
+ * This is the drop-in boundary for the reference's GPU registration path:
+ *
+ *   std::tuple<utils::Matrix<float>, libcpu::point_list>
+ *   libgpu::icp(const point_list& m, const point_list& p, size_t iterations,
+ *               float threshold, uint vp_threshold);          libgpu/libgpu/icp.hh:19-21
+ *
+ * The reference has no C ABI; each entry point below names the reference code it replaces
+ * (paths relative to the reference repository).  A ~40-line C++ shim with the signature above
+ * sits on top of it (integration/libgpu_icp.cc).
+ *
+ * Conventions
+ *   - every function returns 0 (ICP_HIP_OK) or a non-zero icp_hip_status; no exception crosses
+ *     the ABI; icp_hip_last_error(ctx) returns a NUL-terminated message for the last failure on
+ *     that context (icp_hip_last_global_error() for calls that have no context);
+ *   - plain pointers and sizes only; caller-owned buffers stay caller-owned; a context owns its
+ *     device memory, its HIP stream and (optionally) its RCCL communicator;
+ *   - one context drives ONE GPU and must not be used from two threads at once; multi-GPU runs
+ *     are one process (or thread) per GPU, each with its own context holding a contiguous shard
+ *     of the query cloud and a full replica of the tree;
+ *   - points are the reference's Point3D layout: 3 packed floats x,y,z (libcpu/point-3d.hh:12-17);
+ *   - the 4x4 transform is row-major, values[i*4+j] (libcpu/utils/matrix.hh:149).
+ */
+#ifndef ICP_HIP_H
+#define ICP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum icp_hip_status {
+    ICP_HIP_OK = 0,
+    ICP_HIP_ERR_ARG = 1,        /* bad argument / call order                                  */
+    ICP_HIP_ERR_DEGENERATE = 2, /* the cloud hits an undefined-behaviour case of the reference
+                                   tree build (empty side: vp-tree.cc:114-115; capacity <= 2) */
+    ICP_HIP_ERR_HIP = 3,        /* a HIP runtime call or kernel launch failed                 */
+    ICP_HIP_ERR_COMM = 4,       /* RCCL / all-reduce callback failed                          */
+    ICP_HIP_ERR_DEPTH = 5,      /* tree deeper than the traversal stack supports              */
+    ICP_HIP_ERR_NOMEM = 6
+} icp_hip_status;
+
+/* ------------------------------------------------------------------------------------------
+ * Flat structure-of-arrays VP-tree in HOST memory.
+ * Replaces: the pointer tree libcpu::VPTree (libcpu/libcpu/vp-tree.hh:15-49) and its device
+ * image GPUVPTreeNode blob (libgpu/libgpu/vp-tree.hh:69-81, vp-tree.cu:39-112).
+ *
+ * A "child code" c is an internal-node index when c >= 0 and the leaf ~c when c < 0.
+ * A "row" is the index of a point in the cloud the tree was built from.
+ * Every point of the cloud owns exactly one place: an internal node's centre or one bucket slot.
+ * Buckets keep the reference's point order (ties in the leaf scan go to the lowest slot,
+ * vp-tree.cc:131-141); each bucket starts at a multiple of 16 slots, padding slots hold +inf
+ * coordinates and row 0xFFFFFFFF.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct icp_flat_tree {
+    uint64_t n_points; /* == n_nodes + sum(leaf_count)                                        */
+    uint64_t n_slots;  /* bucket slots including padding                                      */
+    uint32_t n_nodes;  /* internal nodes, numbered breadth-first (root == 0 when n_nodes > 0)  */
+    uint32_t n_leaves; /* leaves, numbered left to right (inside before outside)              */
+    uint32_t height;   /* edges on the longest root-to-leaf path                              */
+    uint32_t capacity; /* a node is a leaf iff it holds < capacity points (vp-tree.cc:56)     */
+    uint32_t max_leaf_count;
+    int32_t root;      /* child code of the root                                              */
+    /* internal nodes: n_nodes entries each */
+    const float* node_cx;
+    const float* node_cy;
+    const float* node_cz;
+    const float* node_radius;    /* sqrt(median squared distance), vp-tree.cc:77-78            */
+    const int32_t* node_inside;  /* child code, points with d2 <  r2                            */
+    const int32_t* node_outside; /* child code, points with d2 >= r2                            */
+    const int32_t* node_parent;  /* internal index, -1 for the root                             */
+    const uint32_t* node_row;    /* row of the centre                                           */
+    /* leaves: n_leaves entries each */
+    const uint32_t* leaf_begin; /* first slot                                                   */
+    const uint32_t* leaf_count; /* points in the bucket (>= 1)                                  */
+    /* buckets: n_slots entries each */
+    const float* slot_x;
+    const float* slot_y;
+    const float* slot_z;
+    const uint32_t* slot_row;
+} icp_flat_tree;
+
+/* Host-side tree build: replaces libcpu::VPTree::VPTree (libcpu/libcpu/vp-tree.cc:54-123, with
+ * partition/select/median :7-52) as called from libgpu::icp (libgpu/libgpu/icp.cu:141-142).
+ * `xyz_centered` is the reference cloud already centred on its mean (icp.cu:141 / icp.cc:108).
+ * Produces exactly the reference tree (same centres, radii, bucket contents and order).
+ * Returns ICP_HIP_ERR_DEGENERATE where the reference's build is undefined behaviour. */
+int icp_hip_tree_build(const float* xyz_centered, uint64_t n, uint32_t capacity,
+                       icp_flat_tree** out);
+void icp_hip_tree_free(icp_flat_tree* tree);
+/* Structural check of a caller-made flat tree (ranges, parent/child consistency, every row owned
+ * once).  icp_hip_set_tree runs it before uploading. */
+int icp_hip_tree_validate(const icp_flat_tree* tree);
+
+/* libcpu::mean (libcpu/libcpu/point-3d.cc:177-192): sequential fp32, each term divided by n.
+ * Host helper used for mu_m so that the centred cloud, hence the tree, is the reference's. */
+void icp_hip_mean_host(const float* xyz, uint64_t n, float mu_out[3]);
+/* libcpu::subtract(list, point) (point-3d.cc:194-210). */
+void icp_hip_center_host(const float* xyz, uint64_t n, const float mu[3], float* out_xyz);
+
+/* Rigid-transform solve on the host: 3x3 cross-covariance H (row-major, row = coordinate of the
+ * centred moving cloud, column = coordinate of its matched reference points) -> row-major 4x4
+ * [r t; 0 0 0 1] with r = V U^T (no reflection fix) and t = mu_m - r mu_p.
+ * Replaces libgpu::find_rotation (libgpu/libgpu/svd.cc:7-28, Eigen JacobiSVD) and the
+ * transpose/dot/subtract/to_transformation chain of libgpu/libgpu/icp.cu:35-62; semantics of
+ * libcpu find_alignment + to_transformation (libcpu/libcpu/icp.cc:11-60).  icp_hip_run calls it
+ * once per iteration. */
+void icp_hip_alignment_host(const float H[9], const float mu_p[3], const float mu_m[3],
+                            float T_out[16]);
+
+/* ------------------------------------------------------------------------------------------
+ * Device context
+ * ---------------------------------------------------------------------------------------- */
+typedef struct icp_hip_ctx icp_hip_ctx;
+
+/* Replaces the implicit device state of libgpu (GPUMatrix / GPUVPTree RAII,
+ * libgpu/libgpu/matrix.cu:6-17, vp-tree.cu:7-16).  device_id < 0 means the current device. */
+int icp_hip_create(icp_hip_ctx** out, int device_id);
+void icp_hip_destroy(icp_hip_ctx* ctx);
+const char* icp_hip_last_error(const icp_hip_ctx* ctx);
+const char* icp_hip_last_global_error(void);
+
+/* Upload (one bulk H2D per array) and pack the tree for the kernels.
+ * Replaces GPUVPTree::from_cpu (libgpu/libgpu/vp-tree.cu:58-112).  The tree is borrowed only
+ * for the duration of the call. */
+int icp_hip_set_tree(icp_hip_ctx* ctx, const icp_flat_tree* tree);
+
+/* Upload this context's contiguous shard of the cloud to move ("p", icp.hh:20).
+ * Replaces GPUMatrix::from_point_list (libgpu/libgpu/matrix.cu:95-103).
+ * n_total is the size of the whole cloud over all shards (== n_local on one GPU). */
+int icp_hip_set_queries(icp_hip_ctx* ctx, const float* xyz_aos, uint64_t n_local,
+                        uint64_t n_total);
+
+/* One batch nearest-neighbour pass over the shard: query_i = p_i - mu_p.
+ * Replaces GPUVPTree::closest / closest_kernel (libgpu/libgpu/vp-tree.cu:181-261), with the
+ * CPU rules of VPTree::search (libcpu/libcpu/vp-tree.cc:125-175).
+ * Outputs are host arrays of n_local entries and may each be NULL:
+ *   row_out   row (in the tree's cloud) of the point the reference search returns
+ *   xyz_out   that point's coordinates (what VPTree::closest returns, vp-tree.cc:177-187)
+ *   dist_out  the fp32 distance the reference search returns with it
+ * kernel_ms (may be NULL) receives the HIP-event time of the kernel alone. */
+int icp_hip_nn(icp_hip_ctx* ctx, const float mu_p[3], uint32_t* row_out, float* xyz_out,
+               float* dist_out, float* kernel_ms);
+
+/* All-reduce hook for runs sharded over several contexts: sum `count` doubles in place over all
+ * shards (host memory).  Return 0 on success.  Leave unset (or set RCCL below) for one GPU. */
+typedef int (*icp_hip_allreduce_fn)(double* values, int count, void* user);
+int icp_hip_set_allreduce(icp_hip_ctx* ctx, icp_hip_allreduce_fn fn, void* user);
+
+/* RCCL communicator over xGMI, one rank per context.  unique_id is the 128-byte ncclUniqueId
+ * made by icp_hip_comm_unique_id on rank 0 and distributed by the caller.  When set, the
+ * per-iteration sums are all-reduced on the device on the context's stream. */
+int icp_hip_comm_unique_id(void* unique_id_out, size_t size /* >= 128 */);
+int icp_hip_comm_init_rank(icp_hip_ctx* ctx, int n_ranks, int rank, const void* unique_id,
+                           size_t size);
+
+/* The registration loop: replaces libgpu::icp's loop (libgpu/libgpu/icp.cu:144-158) with the
+ * semantics of libcpu::icp (libcpu/libcpu/icp.cc:110-125):
+ *   for (i = 0; i < max_iters && error > threshold; ++i) { ... }      error starts at +inf
+ * mu_m is mean(m) as icp_hip_mean_host computes it.  progress (may be NULL) is called once per
+ * iteration after the error is known (the reference prints "Starting iter" / "Error:" to
+ * stderr there, icp.cc:112-113,124).  T_out is the accumulated 4x4 (icp.cc:121). */
+typedef void (*icp_hip_progress_fn)(uint64_t iteration /*1-based*/, uint64_t max_iters,
+                                    float error, void* user);
+int icp_hip_run(icp_hip_ctx* ctx, const float mu_m[3], uint64_t max_iters, float threshold,
+                float T_out[16], uint64_t* iters_done, float* final_error,
+                icp_hip_progress_fn progress, void* user);
+
+/* Moved shard, same order as given to icp_hip_set_queries (icp.cu:160 to_point_list). */
+int icp_hip_get_points(icp_hip_ctx* ctx, float* xyz_aos);
+
+/* Phase timers accumulated since the last icp_hip_set_queries (HIP events on the context's
+ * stream; the reference has only gettimeofday around icp(), main.cc:29-40). */
+typedef struct icp_hip_timing {
+    uint64_t nn_launches;
+    double nn_ms;      /* NN + covariance kernel                       */
+    double apply_ms;   /* apply + error + centroid kernel              */
+    double reduce_ms;  /* final reductions of the per-block partials   */
+    double host_ms;    /* wall time of icp_hip_run                     */
+} icp_hip_timing;
+int icp_hip_get_timing(icp_hip_ctx* ctx, icp_hip_timing* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICP_HIP_H */

@@ -74,6 +74,21 @@ class Oracle:
         L.orc_icp.argtypes = [_f32p, u64, _f32p, u64, u64, C.c_float, u32, _f32p, vp,
                               C.POINTER(u64), vp, vp]
         L.orc_icp.restype = C.c_int
+        L.flat_walk_closest.argtypes = [vp, _f32p, u64, vp, vp, vp, vp]
+
+    def flat_walk_closest(self, flat_tree_ptr, q):
+        """Host emulation of the kernel's traversal over an icp_flat_tree (oracle/flat_walk.cc).
+
+        flat_tree_ptr: ctypes pointer to the icp_flat_tree struct."""
+        q = _as_pts(q)
+        n = len(q)
+        ids = np.empty(n, np.uint32)
+        row = np.empty(n, np.uint32)
+        dist = np.empty(n, np.float32)
+        xyz = np.empty((n, 3), np.float32)
+        self.L.flat_walk_closest(C.cast(flat_tree_ptr, C.c_void_p), q, n, ids.ctypes.data,
+                                 row.ctypes.data, dist.ctypes.data, xyz.ctypes.data)
+        return dict(id=ids, row=row, dist=dist, xyz=xyz)
 
     def _free(self, h):
         self.L.orc_tree_free(h)
