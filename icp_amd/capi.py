@@ -22,7 +22,7 @@ EXPORTS = [
     "icp_hip_center_host", "icp_hip_alignment_host", "icp_hip_create", "icp_hip_destroy", "icp_hip_last_error",
     "icp_hip_last_global_error", "icp_hip_set_tree", "icp_hip_set_queries", "icp_hip_nn",
     "icp_hip_set_allreduce", "icp_hip_comm_unique_id", "icp_hip_comm_init_rank", "icp_hip_run",
-    "icp_hip_get_points", "icp_hip_get_timing",
+    "icp_hip_get_points", "icp_hip_get_timing", "icp_hip_get_nn_trace",
 ]
 
 
@@ -49,7 +49,8 @@ class FlatTreeStruct(C.Structure):
 
 class TimingStruct(C.Structure):
     _fields_ = [("nn_launches", C.c_uint64), ("nn_ms", C.c_double), ("apply_ms", C.c_double),
-                ("reduce_ms", C.c_double), ("host_ms", C.c_double)]
+                ("reduce_ms", C.c_double), ("host_ms", C.c_double), ("queries", C.c_double),
+                ("nodes_visited", C.c_double), ("points_scanned", C.c_double)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int, C.c_void_p)
@@ -96,6 +97,7 @@ def load() -> C.CDLL:
                               PROGRESS_FN, vp]
     L.icp_hip_get_points.argtypes = [vp, vp]
     L.icp_hip_get_timing.argtypes = [vp, C.POINTER(TimingStruct)]
+    L.icp_hip_get_nn_trace.argtypes = [vp, vp, u64, C.POINTER(u64)]
     _lib = L
     return L
 
@@ -280,6 +282,16 @@ class Context:
     def get_points(self) -> np.ndarray:
         out = np.empty((self.n_local, 3), np.float32)
         _check(self._L.icp_hip_get_points(self._h, out.ctypes.data), self._h)
+        return out
+
+    def nn_trace(self) -> np.ndarray:
+        """NN-kernel ms of each iteration of the last run()."""
+        cnt = C.c_uint64()
+        _check(self._L.icp_hip_get_nn_trace(self._h, None, 0, C.byref(cnt)), self._h)
+        out = np.zeros(cnt.value, np.float32)
+        if cnt.value:
+            _check(self._L.icp_hip_get_nn_trace(self._h, out.ctypes.data, cnt.value,
+                                                C.byref(cnt)), self._h)
         return out
 
     def timing(self) -> dict:

@@ -136,6 +136,7 @@ struct icp_hip_ctx
     int n_ranks = 1;
 
     icp_hip_timing timing{};
+    std::vector<float> nn_trace; // NN kernel ms of each iteration of the last icp_hip_run
 };
 
 namespace
@@ -529,16 +530,22 @@ extern "C"
             *kernel_ms = 0.f;
         if (n == 0)
             return ICP_HIP_OK;
-        NnLaunch a = make_nn(c, mu_p, true, true, true, false);
+        NnLaunch a = make_nn(c, mu_p, true, true, true, true);
         HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
         HIP_TRY(c, launch_nn(a, c->stream));
         HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+        HIP_TRY(c, launch_reduce_partials(c->partials.p, a.grid, kCovSums, c->sums.p, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->h_sums, c->sums.p, sizeof(double) * kCovSums,
+                                  hipMemcpyDeviceToHost, c->stream));
         if (xyz_out)
             HIP_TRY(c, launch_soa_to_aos(c->yx.p, c->yy.p, c->yz.p, n, c->aos.p, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         const float ms = elapsed_ms(c);
         c->timing.nn_launches += 1;
         c->timing.nn_ms += ms;
+        c->timing.nodes_visited += c->h_sums[9];   // this shard only (no all-reduce here)
+        c->timing.points_scanned += c->h_sums[10];
+        c->timing.queries += (double)n;
         if (kernel_ms)
             *kernel_ms = ms;
         if (row_out)
@@ -618,6 +625,7 @@ extern "C"
         const uint32_t g_nn = nn_grid(n), g_st = stream_grid(n);
         const double n_total = (double)c->n_total;
 
+        c->nn_trace.clear();
         float T[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}; // icp.cc:101
         float error = std::numeric_limits<float>::infinity();           // icp.cc:104
         uint64_t it = 0;
@@ -650,8 +658,16 @@ extern "C"
             HIP_TRY(c, launch_reduce_partials(c->partials.p, g_nn, kCovSums, c->sums.p, c->stream));
             if ((rc = reduce_to_host(c, kCovSums)) != ICP_HIP_OK)
                 return rc;
-            c->timing.nn_ms += elapsed_ms(c);
-            c->timing.nn_launches += 1;
+            {
+                const float ms = elapsed_ms(c);
+                c->timing.nn_ms += ms;
+                c->timing.nn_launches += 1;
+                c->timing.nodes_visited += c->h_sums[9];
+                c->timing.points_scanned += c->h_sums[10];
+                c->timing.queries += (double)c->n_total;
+                if (c->nn_trace.size() < 4096)
+                    c->nn_trace.push_back(ms);
+            }
 
             float H[9], Tn[16], Tt[16];
             for (int k = 0; k < 9; ++k)
@@ -703,6 +719,17 @@ extern "C"
         HIP_TRY(c, hipMemcpyAsync(xyz_aos, c->aos.p, 3ull * n * sizeof(float),
                                   hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return ICP_HIP_OK;
+    }
+
+    int icp_hip_get_nn_trace(icp_hip_ctx* c, float* ms_out, uint64_t capacity, uint64_t* count)
+    {
+        if (!c || !count)
+            return fail(c, ICP_HIP_ERR_ARG, "icp_hip_get_nn_trace: NULL argument");
+        *count = c->nn_trace.size();
+        if (ms_out)
+            for (uint64_t i = 0; i < capacity && i < c->nn_trace.size(); ++i)
+                ms_out[i] = c->nn_trace[i];
         return ICP_HIP_OK;
     }
 

@@ -34,7 +34,9 @@ namespace icp_dev
         float m[12]; // rows 0..2 of the row-major 4x4
     };
 
-    constexpr int kCovSums = 9;   // sum q (x) y, row = P coordinate, col = Y coordinate
+    constexpr int kCovSums = 11;  // [0..8] sum q (x) y (row = P coordinate, col = Y coordinate);
+                                  // [9] internal nodes visited, [10] bucket points scanned
+                                  // (the reference traversal's deterministic work counters)
     constexpr int kApplySums = 4; // error, sum x', sum y', sum z'
     constexpr uint32_t kNnMaxBlocks = 256 * 8;
     constexpr uint32_t kStreamMaxBlocks = 256 * 8;

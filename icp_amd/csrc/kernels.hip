@@ -236,6 +236,7 @@ namespace icp_dev
             }
             int node = t.root, prev = 0, level = 0;
             int mode = kDescend;
+            uint32_t n_int = 0, n_pts = 0; // work counters of this query
             float rd = 0.f;
             uint32_t rid = 0;
             uint32_t lbeg = 0, lcnt = 0;
@@ -246,6 +247,7 @@ namespace icp_dev
                 const uint2 li = t.leaf_info[~t.root];
                 lbeg = li.x;
                 lcnt = li.y;
+                n_pts = li.y;
                 prev = t.root;
                 node = -1;
                 mode = kWaitLeaf;
@@ -259,6 +261,7 @@ namespace icp_dev
                     if (mode <= kReturn)
                     {
                         const DevNode N = t.nodes[node];
+                        n_int += (mode == kDescend) ? 1u : 0u; // each internal node is entered once
                         const float d = sqrtf(sq_dist(qx, qy, qz, N.cx, N.cy, N.cz)); // :147
                         const bool in_near = d < N.r;                                // :148
                         const int nearc = in_near ? N.inside : N.outside;
@@ -320,6 +323,7 @@ namespace icp_dev
                                 const uint2 li = t.leaf_info[~go];
                                 lbeg = li.x;
                                 lcnt = li.y;
+                                n_pts += li.y;
                                 prev = go;
                                 mode = kWaitLeaf;
                             }
@@ -388,6 +392,8 @@ namespace icp_dev
                 acc[6] += (double)__fmul_rn(qz, ox);
                 acc[7] += (double)__fmul_rn(qz, oy);
                 acc[8] += (double)__fmul_rn(qz, oz);
+                acc[9] += (double)n_int;
+                acc[10] += (double)n_pts;
             }
         }
         if (partials)

@@ -180,8 +180,18 @@ typedef struct icp_hip_timing {
     double apply_ms;   /* apply + error + centroid kernel              */
     double reduce_ms;  /* final reductions of the per-block partials   */
     double host_ms;    /* wall time of icp_hip_run                     */
+    /* deterministic work counters of the reference traversal, summed over the NN passes above
+     * (over ALL shards for icp_hip_run, this shard for icp_hip_nn): they price the algorithmic
+     * bytes of the NN kernel, 16 B per query + 16 B per internal node visited + 12 B per bucket
+     * point scanned. */
+    double queries;
+    double nodes_visited;
+    double points_scanned;
 } icp_hip_timing;
 int icp_hip_get_timing(icp_hip_ctx* ctx, icp_hip_timing* out);
+/* NN-kernel milliseconds of each iteration of the last icp_hip_run (first `capacity` entries
+ * copied to ms_out when it is not NULL; *count receives the number of iterations recorded). */
+int icp_hip_get_nn_trace(icp_hip_ctx* ctx, float* ms_out, uint64_t capacity, uint64_t* count);
 
 #ifdef __cplusplus
 }

@@ -75,6 +75,21 @@ class Oracle:
                               C.POINTER(u64), vp, vp]
         L.orc_icp.restype = C.c_int
         L.flat_walk_closest.argtypes = [vp, _f32p, u64, vp, vp, vp, vp]
+        L.orc_tree_from_flat.argtypes = [C.c_int32] + [vp] * 13
+        L.orc_tree_from_flat.restype = vp
+
+    def max_threads(self) -> int:
+        return int(self.L.orc_max_threads())
+
+    def tree_from_flat(self, ft):
+        """Pointer tree for the recursive search from an icp_amd.capi.FlatTree (no rebuild)."""
+        s = ft.struct
+        ptr = lambda name: C.cast(getattr(s, name), C.c_void_p)
+        h = self.L.orc_tree_from_flat(
+            s.root, ptr("node_cx"), ptr("node_cy"), ptr("node_cz"), ptr("node_radius"),
+            ptr("node_inside"), ptr("node_outside"), ptr("node_row"), ptr("leaf_begin"),
+            ptr("leaf_count"), ptr("slot_x"), ptr("slot_y"), ptr("slot_z"), ptr("slot_row"))
+        return _Tree(self, h)
 
     def flat_walk_closest(self, flat_tree_ptr, q):
         """Host emulation of the kernel's traversal over an icp_flat_tree (oracle/flat_walk.cc).

@@ -30,6 +30,8 @@
 #include <memory>
 #include <vector>
 
+#include <omp.h>
+
 namespace
 {
     struct P3
@@ -75,6 +77,8 @@ namespace
         float radius = 0;
         std::vector<TaggedPoint> bucket;
         bool degenerate = false; // an empty side was produced (UB in the reference)
+
+        VPNode() = default; // filled by orc_tree_from_flat
 
         // libcpu/libcpu/vp-tree.cc:54-123
         VPNode(uint32_t capacity, std::vector<TaggedPoint> pts)
@@ -469,6 +473,51 @@ extern "C"
             v[i] = {{pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]}, (uint32_t)i};
         return new VPNode(capacity, std::move(v));
     }
+    // Rebuild the pointer tree from a flat SoA tree (include/icp_hip.h) WITHOUT re-running the
+    // build: lets the CPU baseline time the recursive reference search on trees whose host build
+    // (71 s at 64M points in the reference) would not fit the benchmark's time box.
+    // flat: pointers to the icp_flat_tree arrays, passed one by one to keep this file free of the
+    // product header.
+    void* orc_tree_from_flat(int32_t root, const float* ncx, const float* ncy, const float* ncz,
+                             const float* nr, const int32_t* nin, const int32_t* nout,
+                             const uint32_t* nrow, const uint32_t* lbeg, const uint32_t* lcnt,
+                             const float* sx, const float* sy, const float* sz,
+                             const uint32_t* srow)
+    {
+        struct Rec
+        {
+            static VPNode* make(int32_t code, const float* ncx, const float* ncy, const float* ncz,
+                                const float* nr, const int32_t* nin, const int32_t* nout,
+                                const uint32_t* nrow, const uint32_t* lbeg, const uint32_t* lcnt,
+                                const float* sx, const float* sy, const float* sz,
+                                const uint32_t* srow)
+            {
+                auto* n = new VPNode();
+                if (code < 0)
+                {
+                    const uint32_t l = (uint32_t)~code;
+                    n->bucket.resize(lcnt[l]);
+                    for (uint32_t k = 0; k < lcnt[l]; ++k)
+                    {
+                        const uint64_t s = (uint64_t)lbeg[l] + k;
+                        n->bucket[k] = {{sx[s], sy[s], sz[s]}, srow[s]};
+                    }
+                    return n;
+                }
+                n->center = {{ncx[code], ncy[code], ncz[code]}, nrow[code]};
+                n->radius = nr[code];
+                n->inside.reset(make(nin[code], ncx, ncy, ncz, nr, nin, nout, nrow, lbeg, lcnt, sx,
+                                     sy, sz, srow));
+                n->outside.reset(make(nout[code], ncx, ncy, ncz, nr, nin, nout, nrow, lbeg, lcnt,
+                                      sx, sy, sz, srow));
+                return n;
+            }
+        };
+        return Rec::make(root, ncx, ncy, ncz, nr, nin, nout, nrow, lbeg, lcnt, sx, sy, sz, srow);
+    }
+
+    int orc_max_threads() { return omp_get_max_threads(); }
+
     void orc_tree_free(void* t)
     {
         delete static_cast<VPNode*>(t);

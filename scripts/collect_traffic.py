@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""HBM traffic of the NN kernel from two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE),
+collected and corrected as MI355X_MICROARCH.md (HBM section) prescribes:
+  * counters are reported in KiB -> x1024;
+  * on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a coalesced streaming read; the
+    factor is CALIBRATED in the same run on sum_points_kernel, which reads exactly 12*n bytes with
+    the NN kernel's own access shape (one dword per lane, 256 B per wave-instruction);
+  * WRITE_SIZE is taken as is.
+Usage: collect_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> \
+           --points N --workload 64M --out profiles/nn_traffic.json
+"""
+import argparse
+import csv
+import json
+
+ap = argparse.ArgumentParser()
+ap.add_argument("fetch_csv")
+ap.add_argument("write_csv")
+ap.add_argument("--points", type=int, required=True, help="points in the shard (sum_points reads 12 B each)")
+ap.add_argument("--workload", default="64M")
+ap.add_argument("--out", default=None)
+ap.add_argument("--steps", type=int, default=0, help="average over the last K launches (bench.py timed region)")
+a = ap.parse_args()
+
+
+def load(path, counter):
+    out = {}
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            out.setdefault(r["Kernel_Name"].split("(")[0], []).append(float(r["Counter_Value"]) * 1024.0)
+    return out
+
+
+f, w = load(a.fetch_csv, "FETCH_SIZE"), load(a.write_csv, "WRITE_SIZE")
+cal = [k for k in f if "sum_points_kernel" in k][0]
+factor = 12.0 * a.points / (sum(f[cal]) / len(f[cal]))
+nn = [k for k in f if "nn_cov_kernel" in k][0]
+fetch = [v * factor for v in f[nn]]
+write = w[nn]
+if a.steps:
+    fetch, write = fetch[-a.steps:], write[-a.steps:]
+res = {
+    "workload": a.workload, "n_gpus": 1, "kernel": nn,
+    "fetch_size_calibration": {"kernel": cal, "known_bytes": 12 * a.points,
+                               "reported_bytes": sum(f[cal]) / len(f[cal]), "factor": factor},
+    "launches": len(fetch),
+    "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
+    "hbm_bytes_per_launch": (sum(fetch) + sum(write)) / len(fetch),
+}
+print(json.dumps(res, indent=1))
+if a.out:
+    json.dump(res, open(a.out, "w"), indent=1)
