@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
 #include <limits>
@@ -125,6 +126,8 @@ struct icp_hip_ctx
     bool has_queries = false;
     DevBuf<float> px, py, pz, yx, yy, yz, aos, dist;
     DevBuf<uint32_t> row;
+    DevBuf<uint32_t> perm; // sorted position -> input row (Morton order), empty when unsorted
+    bool sorted = false;
     DevBuf<double> partials, sums;
     double* h_sums = nullptr; // pinned, 16 doubles
 
@@ -231,9 +234,70 @@ namespace
         a.yz = want_y ? c->yz.p : nullptr;
         a.row_out = want_row ? c->row.p : nullptr;
         a.dist_out = want_dist ? c->dist.p : nullptr;
+        a.perm = c->sorted ? c->perm.p : nullptr;
         a.partials = want_cov ? c->partials.p : nullptr;
         a.grid = nn_grid(c->n_local);
         return a;
+    }
+
+    // Store the shard in Morton order of its positions (sort.hip); c->aos holds the input AoS.
+    int sort_queries(icp_hip_ctx* c, uint32_t n)
+    {
+        const uint32_t grid = stream_grid(n);
+        DevBuf<float> mm;
+        DevBuf<uint32_t> keys, keys2, idx;
+        struct Cleanup
+        {
+            DevBuf<float>& a;
+            DevBuf<uint32_t>&b, &d, &e;
+            ~Cleanup()
+            {
+                a.release();
+                b.release();
+                d.release();
+                e.release();
+            }
+        } cleanup{mm, keys, keys2, idx};
+        HIP_TRY(c, mm.alloc((size_t)grid * 6));
+        HIP_TRY(c, keys.alloc(n));
+        HIP_TRY(c, keys2.alloc(n));
+        HIP_TRY(c, idx.alloc(n));
+        HIP_TRY(c, c->perm.alloc(n));
+        HIP_TRY(c, launch_minmax(c->aos.p, n, grid, mm.p, c->stream));
+        std::vector<float> h((size_t)grid * 6);
+        HIP_TRY(c, hipMemcpyAsync(h.data(), mm.p, h.size() * sizeof(float), hipMemcpyDeviceToHost,
+                                  c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        float lo[3], hi[3], scale[3];
+        for (int k = 0; k < 3; ++k)
+        {
+            lo[k] = h[k];
+            hi[k] = h[3 + k];
+        }
+        for (uint32_t b = 1; b < grid; ++b)
+            for (int k = 0; k < 3; ++k)
+            {
+                lo[k] = std::fmin(lo[k], h[b * 6 + k]);
+                hi[k] = std::fmax(hi[k], h[b * 6 + 3 + k]);
+            }
+        // one cubic cell size for all axes keeps the Z-curve isotropic
+        float ext = 0.f;
+        for (int k = 0; k < 3; ++k)
+            ext = std::fmax(ext, hi[k] - lo[k]);
+        const bool finite = std::isfinite(ext) && std::isfinite(lo[0]) && std::isfinite(lo[1]) &&
+                            std::isfinite(lo[2]);
+        for (int k = 0; k < 3; ++k)
+        {
+            scale[k] = (finite && ext > 0.f) ? 1024.f / ext : 0.f;
+            if (!finite)
+                lo[k] = 0.f;
+        }
+        HIP_TRY(c, launch_morton(c->aos.p, n, lo, scale, keys.p, idx.p, c->stream));
+        HIP_TRY(c, sort_pairs_u32(keys.p, keys2.p, idx.p, c->perm.p, n, c->stream));
+        HIP_TRY(c, launch_gather_soa(c->aos.p, c->perm.p, n, c->px.p, c->py.p, c->pz.p, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->sorted = true;
+        return ICP_HIP_OK;
     }
 } // namespace
 
@@ -375,6 +439,7 @@ extern "C"
         c->aos.release();
         c->dist.release();
         c->row.release();
+        c->perm.release();
         c->partials.release();
         c->sums.release();
         if (c->h_sums)
@@ -502,12 +567,22 @@ extern "C"
         HIP_TRY(c, c->row.alloc(n));
         HIP_TRY(c, c->dist.alloc(n));
         HIP_TRY(c, c->partials.alloc((size_t)kNnMaxBlocks * kCovSums));
+        c->sorted = false;
         if (n_local)
         {
             HIP_TRY(c, hipMemcpyAsync(c->aos.p, xyz_aos, 3 * n_local * sizeof(float),
                                       hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(c, launch_aos_to_soa(c->aos.p, (uint32_t)n_local, c->px.p, c->py.p, c->pz.p,
-                                         c->stream));
+            const char* env = std::getenv("ICP_HIP_SORT_QUERIES");
+            const bool want_sort = !(env && env[0] == '0') && n_local >= 1024;
+            if (want_sort)
+            {
+                int rc = sort_queries(c, (uint32_t)n_local);
+                if (rc != ICP_HIP_OK)
+                    return rc;
+            }
+            else
+                HIP_TRY(c, launch_aos_to_soa(c->aos.p, (uint32_t)n_local, c->px.p, c->py.p,
+                                             c->pz.p, c->stream));
         }
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->n_local = n_local;
@@ -538,7 +613,13 @@ extern "C"
         HIP_TRY(c, hipMemcpyAsync(c->h_sums, c->sums.p, sizeof(double) * kCovSums,
                                   hipMemcpyDeviceToHost, c->stream));
         if (xyz_out)
-            HIP_TRY(c, launch_soa_to_aos(c->yx.p, c->yy.p, c->yz.p, n, c->aos.p, c->stream));
+        {
+            if (c->sorted)
+                HIP_TRY(c, launch_scatter_aos(c->yx.p, c->yy.p, c->yz.p, c->perm.p, n, c->aos.p,
+                                              c->stream));
+            else
+                HIP_TRY(c, launch_soa_to_aos(c->yx.p, c->yy.p, c->yz.p, n, c->aos.p, c->stream));
+        }
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         const float ms = elapsed_ms(c);
         c->timing.nn_launches += 1;
@@ -715,7 +796,11 @@ extern "C"
             return fail(c, ICP_HIP_ERR_ARG, "icp_hip_get_points: xyz_aos is NULL");
         DeviceGuard g(c->device);
         const uint32_t n = (uint32_t)c->n_local;
-        HIP_TRY(c, launch_soa_to_aos(c->px.p, c->py.p, c->pz.p, n, c->aos.p, c->stream));
+        if (c->sorted)
+            HIP_TRY(c, launch_scatter_aos(c->px.p, c->py.p, c->pz.p, c->perm.p, n, c->aos.p,
+                                          c->stream));
+        else
+            HIP_TRY(c, launch_soa_to_aos(c->px.p, c->py.p, c->pz.p, n, c->aos.p, c->stream));
         HIP_TRY(c, hipMemcpyAsync(xyz_aos, c->aos.p, 3ull * n * sizeof(float),
                                   hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -52,6 +52,7 @@ namespace icp_dev
         float *yx, *yy, *yz; // may be null together
         uint32_t* row_out;   // may be null
         float* dist_out;     // may be null
+        const uint32_t* perm; // may be null: row_out/dist_out are written at perm[i] (input order)
         double* partials;    // [grid][kCovSums] or null
         uint32_t grid;
     };
@@ -72,6 +73,18 @@ namespace icp_dev
                                  hipStream_t s);
     hipError_t launch_soa_to_aos(const float* x, const float* y, const float* z, uint32_t n,
                                  float* aos, hipStream_t s);
+    // sort.hip: Morton ordering of the cloud to move
+    hipError_t launch_minmax(const float* aos, uint32_t n, uint32_t grid, float* partials,
+                             hipStream_t s);
+    hipError_t launch_morton(const float* aos, uint32_t n, const float lo[3], const float scale[3],
+                             uint32_t* keys, uint32_t* idx, hipStream_t s);
+    hipError_t sort_pairs_u32(const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* idx_in,
+                              uint32_t* idx_out, uint32_t n, hipStream_t s);
+    hipError_t launch_gather_soa(const float* aos, const uint32_t* perm, uint32_t n, float* x,
+                                 float* y, float* z, hipStream_t s);
+    hipError_t launch_scatter_aos(const float* x, const float* y, const float* z,
+                                  const uint32_t* perm, uint32_t n, float* aos, hipStream_t s);
+
     hipError_t launch_pack_nodes(const float* cx, const float* cy, const float* cz, const float* r,
                                  const int32_t* inside, const int32_t* outside,
                                  const int32_t* parent, const uint32_t* row, uint32_t n,

@@ -204,7 +204,7 @@ namespace icp_dev
                       const float* __restrict__ pz, float mux, float muy, float muz, uint32_t n,
                       float* __restrict__ yx, float* __restrict__ yy, float* __restrict__ yz,
                       uint32_t* __restrict__ row_out, float* __restrict__ dist_out,
-                      double* __restrict__ partials)
+                      const uint32_t* __restrict__ perm, double* __restrict__ partials)
     {
         __shared__ float s_near_d[kWavesPerBlock * MAXD * kWave];
         __shared__ uint32_t s_near_i[kWavesPerBlock * MAXD * kWave];
@@ -378,10 +378,14 @@ namespace icp_dev
                     yy[i] = oy;
                     yz[i] = oz;
                 }
-                if (row_out)
-                    row_out[i] = row;
-                if (dist_out)
-                    dist_out[i] = rd;
+                if (row_out || dist_out)
+                {
+                    const uint32_t o = perm ? perm[i] : i; // back to the caller's order
+                    if (row_out)
+                        row_out[o] = row;
+                    if (dist_out)
+                        dist_out[o] = rd;
+                }
                 // fp32 products as find_covariance forms them (point-3d.cc:220-231), summed in fp64
                 acc[0] += (double)__fmul_rn(qx, ox);
                 acc[1] += (double)__fmul_rn(qx, oy);
@@ -540,7 +544,7 @@ namespace icp_dev
         const dim3 g(a.grid), b(kBlock);
 #define ICP_NN_GO(NCH)                                                                          \
     hipLaunchKernelGGL((nn_cov_kernel<MAXD, NCH>), g, b, 0, s, a.tree, a.px, a.py, a.pz, a.mu[0], \
-                       a.mu[1], a.mu[2], a.n, a.yx, a.yy, a.yz, a.row_out, a.dist_out, a.partials)
+                       a.mu[1], a.mu[2], a.n, a.yx, a.yy, a.yz, a.row_out, a.dist_out, a.perm, a.partials)
         if (a.max_leaf_count <= 64)
             ICP_NN_GO(1);
         else if (a.max_leaf_count <= 128)
