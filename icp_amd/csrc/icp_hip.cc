@@ -132,6 +132,14 @@ struct icp_hip_ctx
     double* h_sums = nullptr; // pinned, 16 doubles
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    uint32_t tile_blocks = 0;   // resident nn_tile_kernel workgroups on this device (multiple of 8)
+    bool force_deep = false;    // ICP_HIP_NN_KERNEL=deep: always run nn_cov_kernel
+    // nn_tile_kernel work queue / per-chunk sums / overflow stack (sized by prepare_tile)
+    DevBuf<uint32_t> queue;
+    DevBuf<double> chunk_sums;
+    DevBuf<uint2> spill;
+    uint32_t chunk_batches = 1, n_chunks = 0, tile_grid_blocks = 8, spill_levels = 0;
+    bool tile_ready = false;
 
     icp_hip_allreduce_fn allreduce = nullptr;
     void* allreduce_user = nullptr;
@@ -238,6 +246,76 @@ namespace
         a.partials = want_cov ? c->partials.p : nullptr;
         a.grid = nn_grid(c->n_local);
         return a;
+    }
+
+    // Size the tile kernel's launch for the current tree + shard (called when either changes;
+    // allocates, so never from the iteration loop).
+    int prepare_tile(icp_hip_ctx* c)
+    {
+        c->tile_ready = false;
+        if (!c->has_tree || !c->has_queries || c->n_local == 0)
+            return ICP_HIP_OK;
+        const uint64_t batches = (c->n_local + 63) / 64;
+        // every workgroup resident; at least one batch per wave
+        uint64_t g = (batches + 3) / 4;
+        if (g > c->tile_blocks)
+            g = c->tile_blocks;
+        c->tile_grid_blocks = (uint32_t)(g < 1 ? 1 : g);
+        // chunks: ~8 per wave for load balance, at most 8 batches each
+        uint64_t cb = batches / ((uint64_t)c->tile_grid_blocks * 4 * 8);
+        c->chunk_batches = (uint32_t)(cb < 1 ? 1 : (cb > 8 ? 8 : cb));
+        c->n_chunks = (uint32_t)((batches + c->chunk_batches - 1) / c->chunk_batches);
+        const uint32_t k = nn_tile_stack_entries();
+        c->spill_levels = c->height > k ? c->height - k : 0;
+        HIP_TRY(c, c->queue.alloc(kQueueWords));
+        HIP_TRY(c, c->chunk_sums.alloc((size_t)c->n_chunks * kCovSums));
+        HIP_TRY(c, c->spill.alloc((size_t)c->spill_levels * c->tile_grid_blocks * 256));
+        c->tile_ready = true;
+        return ICP_HIP_OK;
+    }
+
+    // One NN + covariance pass over the shard.  Leaves the kCovSums sums (all-reduced over the
+    // shards when `allreduce`) in c->h_sums and the kernel time in *ms.
+    int nn_pass(icp_hip_ctx* c, NnLaunch a, bool allreduce, float* ms)
+    {
+        const bool deep = c->force_deep || !c->tile_ready;
+        *ms = 0.f;
+        if (deep)
+        {
+            a.grid = nn_grid(c->n_local);
+            HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+            HIP_TRY(c, launch_nn(a, c->stream));
+            HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+            HIP_TRY(c, launch_reduce_partials(c->partials.p, a.grid, kCovSums, c->sums.p, c->stream));
+        }
+        else
+        {
+            a.grid = c->tile_grid_blocks;
+            TileLaunch q{c->chunk_batches, c->chunk_sums.p, c->queue.p, c->spill.p};
+            HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+            HIP_TRY(c, launch_nn_tile(a, q, c->stream));
+            HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+            // chunk sums -> <= 1024 partial rows -> the twelve sums, both in a fixed order
+            uint32_t g1 = (c->n_chunks + 63) / 64;
+            g1 = g1 > 1024 ? 1024 : g1;
+            HIP_TRY(c, launch_reduce_rows(c->chunk_sums.p, c->n_chunks, kCovSums, g1, c->partials.p,
+                                          c->stream));
+            HIP_TRY(c, launch_reduce_partials(c->partials.p, g1, kCovSums, c->sums.p, c->stream));
+        }
+        if (allreduce)
+        {
+            int rc = reduce_to_host(c, kCovSums);
+            if (rc != ICP_HIP_OK)
+                return rc;
+        }
+        else
+        {
+            HIP_TRY(c, hipMemcpyAsync(c->h_sums, c->sums.p, sizeof(double) * kCovSums,
+                                      hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
+        *ms = elapsed_ms(c);
+        return ICP_HIP_OK;
     }
 
     // Store the shard in Morton order of its positions (sort.hip); c->aos holds the input AoS.
@@ -411,6 +489,20 @@ extern "C"
             return bail(e, "hipHostMalloc");
         if ((e = c->sums.alloc(16)) != hipSuccess)
             return bail(e, "hipMalloc(sums)");
+        {
+            int per_cu = 0, cus = 0;
+            if ((e = nn_tile_blocks_per_cu(&per_cu)) != hipSuccess)
+                return bail(e, "hipOccupancyMaxActiveBlocksPerMultiprocessor");
+            if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount,
+                                           device_id)) != hipSuccess)
+                return bail(e, "hipDeviceGetAttribute");
+            uint64_t blocks = (uint64_t)(per_cu > 0 ? per_cu : 1) * (uint64_t)(cus > 0 ? cus : 1);
+            if (blocks > kNnMaxBlocks)
+                blocks = kNnMaxBlocks;
+            c->tile_blocks = (uint32_t)blocks;
+            const char* env = std::getenv("ICP_HIP_NN_KERNEL");
+            c->force_deep = env && std::strcmp(env, "deep") == 0;
+        }
         *out = c;
         return ICP_HIP_OK;
     }
@@ -440,6 +532,9 @@ extern "C"
         c->dist.release();
         c->row.release();
         c->perm.release();
+        c->queue.release();
+        c->chunk_sums.release();
+        c->spill.release();
         c->partials.release();
         c->sums.release();
         if (c->h_sums)
@@ -471,7 +566,7 @@ extern "C"
         DeviceGuard g(c->device);
         c->has_tree = false;
         const size_t nn = t->n_nodes, nl = t->n_leaves, ns = t->n_slots;
-        const size_t slack = 64; // scan_bucket may read one wave past a bucket's last chunk
+        const size_t slack = kSlotSlack; // bucket windows / chunks are loaded whole
 
         // staging for the SoA node arrays, packed into 32-byte records on the device
         DevBuf<float> f4[4];
@@ -540,7 +635,7 @@ extern "C"
         c->max_leaf = t->max_leaf_count;
         c->n_tree_points = t->n_points;
         c->has_tree = true;
-        return ICP_HIP_OK;
+        return prepare_tile(c);
     }
 
     int icp_hip_set_queries(icp_hip_ctx* c, const float* xyz_aos, uint64_t n_local,
@@ -589,7 +684,7 @@ extern "C"
         c->n_total = n_total;
         c->has_queries = true;
         c->timing = icp_hip_timing{};
-        return ICP_HIP_OK;
+        return prepare_tile(c);
     }
 
     int icp_hip_nn(icp_hip_ctx* c, const float mu_p[3], uint32_t* row_out, float* xyz_out,
@@ -606,12 +701,12 @@ extern "C"
         if (n == 0)
             return ICP_HIP_OK;
         NnLaunch a = make_nn(c, mu_p, true, true, true, true);
-        HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-        HIP_TRY(c, launch_nn(a, c->stream));
-        HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-        HIP_TRY(c, launch_reduce_partials(c->partials.p, a.grid, kCovSums, c->sums.p, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(c->h_sums, c->sums.p, sizeof(double) * kCovSums,
-                                  hipMemcpyDeviceToHost, c->stream));
+        float ms = 0.f;
+        {
+            int rc = nn_pass(c, a, false, &ms);
+            if (rc != ICP_HIP_OK)
+                return rc;
+        }
         if (xyz_out)
         {
             if (c->sorted)
@@ -621,7 +716,6 @@ extern "C"
                 HIP_TRY(c, launch_soa_to_aos(c->yx.p, c->yy.p, c->yz.p, n, c->aos.p, c->stream));
         }
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        const float ms = elapsed_ms(c);
         c->timing.nn_launches += 1;
         c->timing.nn_ms += ms;
         c->timing.nodes_visited += c->h_sums[9];   // this shard only (no all-reduce here)
@@ -703,7 +797,7 @@ extern "C"
         DeviceGuard g(c->device);
         const auto t_begin = std::chrono::steady_clock::now();
         const uint32_t n = (uint32_t)c->n_local;
-        const uint32_t g_nn = nn_grid(n), g_st = stream_grid(n);
+        const uint32_t g_st = stream_grid(n);
         const double n_total = (double)c->n_total;
 
         c->nn_trace.clear();
@@ -733,14 +827,10 @@ extern "C"
         {
             // y = tree.closest(p - mu_p); H = sum (p - mu_p) (x) y      icp.cc:115-117, :32-33
             NnLaunch a = make_nn(c, mu_p, true, false, false, true);
-            HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-            HIP_TRY(c, launch_nn(a, c->stream));
-            HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-            HIP_TRY(c, launch_reduce_partials(c->partials.p, g_nn, kCovSums, c->sums.p, c->stream));
-            if ((rc = reduce_to_host(c, kCovSums)) != ICP_HIP_OK)
+            float ms = 0.f;
+            if ((rc = nn_pass(c, a, true, &ms)) != ICP_HIP_OK)
                 return rc;
             {
-                const float ms = elapsed_ms(c);
                 c->timing.nn_ms += ms;
                 c->timing.nn_launches += 1;
                 c->timing.nodes_visited += c->h_sums[9];

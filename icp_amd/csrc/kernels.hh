@@ -20,7 +20,7 @@ namespace icp_dev
     {
         const DevNode* nodes;
         const uint2* leaf_info; // {first slot, count}
-        const float* sx;        // bucket slots (+64 slots of slack behind n_slots)
+        const float* sx;        // bucket slots (+kSlotSlack slots of +inf behind n_slots)
         const float* sy;
         const float* sz;
         const uint32_t* srow;
@@ -34,11 +34,13 @@ namespace icp_dev
         float m[12]; // rows 0..2 of the row-major 4x4
     };
 
-    constexpr int kCovSums = 11;  // [0..8] sum q (x) y (row = P coordinate, col = Y coordinate);
+    constexpr int kCovSums = 12;  // [0..8] sum q (x) y (row = P coordinate, col = Y coordinate);
                                   // [9] internal nodes visited, [10] bucket points scanned
-                                  // (the reference traversal's deterministic work counters)
+                                  // (the reference traversal's deterministic work counters);
+                                  // [11] stack entries nn_tile_kernel spilled from LDS to HBM
     constexpr int kApplySums = 4; // error, sum x', sum y', sum z'
     constexpr uint32_t kNnMaxBlocks = 256 * 8;
+    constexpr uint32_t kSlotSlack = 256; // a staged bucket window may read this far past a bucket
     constexpr uint32_t kStreamMaxBlocks = 256 * 8;
 
     struct NnLaunch
@@ -62,6 +64,21 @@ namespace icp_dev
     uint32_t stream_grid(uint64_t n);
 
     hipError_t launch_nn(const NnLaunch& a, hipStream_t s);
+    // nn_tile.hip: the production kernel (a.partials is not used: sums go to q.chunk_sums)
+    constexpr uint32_t kQueueWords = 256; // 8 queue heads, one per 128-byte line
+    struct TileLaunch
+    {
+        uint32_t chunk_batches; // 64-query batches per chunk (1..8)
+        double* chunk_sums;     // [n_chunks][kCovSums] or null
+        uint32_t* queue;        // kQueueWords words, zeroed by the launch
+        uint2* spill;           // [max(0, height - stack entries)][grid * 256] or null
+    };
+    hipError_t launch_nn_tile(const NnLaunch& a, const TileLaunch& q, hipStream_t s);
+    hipError_t nn_tile_blocks_per_cu(int* out);
+    uint32_t nn_tile_stack_entries();
+    // out[b][k] = sum of rows [b*rows_per_block, ...) of rows[n_rows][K], fixed order; K <= 16
+    hipError_t launch_reduce_rows(const double* rows, uint32_t n_rows, int K, uint32_t grid,
+                                  double* out, hipStream_t s);
     hipError_t launch_apply_error(float* px, float* py, float* pz, const float* yx, const float* yy,
                                   const float* yz, const Mat34& T, const float mu_m[3], uint32_t n,
                                   uint32_t grid, double* partials, hipStream_t s);

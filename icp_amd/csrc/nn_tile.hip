@@ -1,0 +1,584 @@
+// nn_tile_kernel -- the production NN + cross-covariance kernel (gfx950, wave = 64).
+//
+// Same contract as nn_cov_kernel (kernels.hip): VPTree::search for every query of the shard
+// (libcpu/libcpu/vp-tree.cc:125-187), bit for bit, + the nine sums of find_covariance
+// (libcpu/libcpu/point-3d.cc:212-236).  What differs is how the work is laid on the machine, for
+// a shard that is stored in a spatially coherent order (sort.hip):
+//
+//  * persistent grid; the shard is cut into chunks of 1..8 consecutive 64-query batches and every
+//    wave pulls chunks from a queue.  There is one queue head per XCD group (blockIdx % 8,
+//    round-robin dispatch) over one eighth of the shard each, so the waves of an XCD work on
+//    neighbouring chunks at the same time (a bucket is fetched from HBM about once and then
+//    lives in that XCD's L2); a group that runs dry steals from the others (load balance);
+//  * every chunk writes its own twelve fp64 sums and two small kernels add the chunks in a fixed
+//    order: the result does not depend on which wave ran which chunk (bitwise reproducible);
+//  * the traversal stack holds only the near-side answers of the levels whose far side is being
+//    searched (push on the way into the far side, pop on the way back): 7 entries per lane in
+//    LDS instead of one per tree level; deeper nestings spill to a per-lane column in HBM
+//    (counted in sum [11]);
+//  * leaf buckets are scanned by (queries x bucket parts) tiles: the g lanes of a wave that wait
+//    on the SAME bucket are served together.  The bucket is staged once in LDS (three 16-byte
+//    loads per lane), the g queries are replicated over P = 64 / pow2(g) lane groups, group p
+//    scans part p of the bucket for all g queries (LDS float4 reads, conflict free by
+//    construction), and the partial minima are folded across the groups.  g = 1 degenerates to
+//    the whole wave scanning for one query, g = 64 to one lane per query.
+//
+// Exactness of the bucket scan.  The reference keeps the first slot that minimises
+// sqrt(d2) under strict < (vp-tree.cc:131-143); two different d2 may share one sqrt.  The tile
+// tracks per query the smallest d2 (m), its first slot, and the second smallest d2 counted with
+// multiplicity (m2).  If m2 is more than 4 ulps above m, sqrt(m2) > sqrt(m) after rounding
+// (the roots are >= 1.41 ulps of the root apart), so the slot of m is the reference's answer and
+// its distance is sqrt(m).  Otherwise (about 1e-4 of the scans) the lane is re-served by the exact
+// wave-cooperative scan of device_common.hh.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_common.hh"
+#include "kernels.hh"
+
+namespace icp_dev
+{
+    namespace
+    {
+        constexpr int kStackK = 7;  // LDS stack entries per lane
+        constexpr int kImage = 256; // bucket slots staged per window
+        constexpr int kTileMinGroup = 3; // fewer lanes on a bucket: whole-wave scan per lane
+
+        enum : int
+        {
+            tDescend = 0, // arriving at `node` from its parent
+            tReturn = 1,  // arriving at `node` from child `prev`, (rd, rid) = that child's answer
+            tWaitLeaf = 2,
+            tWaitExact = 3,
+            tServed = 4, // rd holds the SQUARED distance of the answer, sqrt pending
+            tDone = 5
+        };
+
+        struct __attribute__((aligned(16))) WaveLds
+        {
+            float st_d[kStackK * kWave];
+            uint32_t st_i[kStackK * kWave];
+            float bx[kImage], by[kImage], bz[kImage];
+            float4 qb[kWave]; // queries by rank in the group, then their results
+            double sums[kCovSums + 4]; // this wave's running totals (fixed summation order)
+        };
+        static_assert(sizeof(WaveLds) <= 8192, "LDS budget: 4 waves x 8 KiB = 32 KiB per workgroup");
+
+        __device__ __forceinline__ void wave_lds_fence()
+        {
+            // LDS operations of one wave execute in order; this only pins the compiler
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+
+        __device__ __forceinline__ void track(float d2, uint32_t k, float& m, float& m2,
+                                              uint32_t& idx)
+        {
+            idx = (d2 < m) ? k : idx;
+            m2 = __builtin_amdgcn_fmed3f(m, m2, d2); // m <= m2: second smallest of {m, m2, d2}
+            m = fminf(m, d2);
+        }
+
+        // Tile scan of bucket [beg, beg+cnt) for the lanes in `grp` (all of them wait on it).
+        // On return every member lane has (m, m2, slot-in-bucket of m).
+        __device__ __forceinline__ void tile_scan(const DevTree& t, WaveLds& L, uint32_t beg,
+                                                  uint32_t cnt, uint64_t grp, bool member, float qx,
+                                                  float qy, float qz, int lane, float& out_m,
+                                                  float& out_m2, uint32_t& out_idx)
+        {
+            const float kInf = __int_as_float(0x7f800000);
+            const uint32_t g = (uint32_t)__builtin_popcountll(grp);
+            // gp = pow2 >= g, lg = log2(gp)
+            const uint32_t lg = (g <= 1u) ? 0u : (32u - (uint32_t)__builtin_clz(g - 1u));
+            const uint32_t gp = 1u << lg;
+            const uint32_t P = 64u >> lg;
+            const uint32_t part = (uint32_t)lane >> lg;
+
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(
+                (uint32_t)(grp >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)grp, 0u));
+            if (member)
+                L.qb[rank] = make_float4(qx, qy, qz, 0.f);
+
+            float m = kInf, m2 = kInf;
+            uint32_t idx = 0;
+#pragma nounroll
+            for (uint32_t w0 = 0; w0 < cnt; w0 += kImage) // one window unless the bucket is > 256
+            {
+                const uint32_t cw = min((uint32_t)kImage, cnt - w0);
+                // ---- stage the window: x is +inf in every slot that is not the bucket's ----
+                {
+                    const uint32_t s0 = 4u * (uint32_t)lane;
+                    float4 vx = make_float4(kInf, kInf, kInf, kInf);
+                    float4 vy = make_float4(0.f, 0.f, 0.f, 0.f), vz = vy;
+                    if (s0 < cw)
+                    {
+                        const size_t o = (size_t)beg + w0 + s0;
+                        vx = *reinterpret_cast<const float4*>(t.sx + o);
+                        vy = *reinterpret_cast<const float4*>(t.sy + o);
+                        vz = *reinterpret_cast<const float4*>(t.sz + o);
+                        vx.y = (s0 + 1u < cw) ? vx.y : kInf;
+                        vx.z = (s0 + 2u < cw) ? vx.z : kInf;
+                        vx.w = (s0 + 3u < cw) ? vx.w : kInf;
+                    }
+                    *reinterpret_cast<float4*>(L.bx + s0) = vx;
+                    *reinterpret_cast<float4*>(L.by + s0) = vy;
+                    *reinterpret_cast<float4*>(L.bz + s0) = vz;
+                }
+                wave_lds_fence();
+                const float4 q = L.qb[lane & (gp - 1u)];
+                // part p scans slots [p*len, (p+1)*len) of the window; P*len <= 256
+                const uint32_t len = (((cw + P - 1u) >> (6u - lg)) + 3u) & ~3u;
+                const uint32_t pbase = part * len;
+                const float* bx = L.bx + pbase;
+                const float* by = L.by + pbase;
+                const float* bz = L.bz + pbase;
+                const float m_before = m;
+                uint32_t kbest = 0;
+#pragma nounroll
+                for (uint32_t k = 0; k < len; k += 4)
+                {
+                    const float4 X = *reinterpret_cast<const float4*>(bx + k);
+                    const float4 Y = *reinterpret_cast<const float4*>(by + k);
+                    const float4 Z = *reinterpret_cast<const float4*>(bz + k);
+                    track(sq_dist(q.x, q.y, q.z, X.x, Y.x, Z.x), k, m, m2, kbest);
+                    track(sq_dist(q.x, q.y, q.z, X.y, Y.y, Z.y), k + 1u, m, m2, kbest);
+                    track(sq_dist(q.x, q.y, q.z, X.z, Y.z, Z.z), k + 2u, m, m2, kbest);
+                    track(sq_dist(q.x, q.y, q.z, X.w, Y.w, Z.w), k + 3u, m, m2, kbest);
+                }
+                idx = (m < m_before) ? (w0 + pbase + kbest) : idx;
+                wave_lds_fence(); // the next window overwrites the image
+            }
+            // ---- fold the parts: lane l takes lane l + D, D = gp, 2gp, .. 32 ----
+#pragma nounroll
+            for (uint32_t D = gp; D < 64u; D <<= 1)
+            {
+                const float mb = __shfl_down(m, D, kWave);
+                const float m2b = __shfl_down(m2, D, kWave);
+                const uint32_t ib = __shfl_down(idx, D, kWave);
+                idx = (mb < m) ? ib : idx;
+                m2 = fminf(fminf(m2, m2b), fmaxf(m, mb));
+                m = fminf(m, mb);
+            }
+            if ((uint32_t)lane < g)
+                L.qb[lane] = make_float4(m, m2, __uint_as_float(idx), 0.f);
+            wave_lds_fence();
+            const float4 r = L.qb[member ? rank : 0u];
+            out_m = r.x;
+            out_m2 = r.y;
+            out_idx = __float_as_uint(r.z);
+            wave_lds_fence();
+        }
+
+
+        // Whole-wave scan of one bucket of <= 256 slots for ONE query (arguments wave-uniform):
+        // the cheaper form when only one or two lanes wait on the bucket.  All chunk loads are
+        // issued before the first use.  Returns the SQUARED distance of the reference's answer
+        // (its sqrt is the reference's distance) and the answer's slot.
+        __device__ __forceinline__ void coop_scan(const DevTree& t, float bx, float by, float bz,
+                                                  uint32_t beg, uint32_t cnt, int lane, float& m_out,
+                                                  uint32_t& win_out)
+        {
+            const float kInf = __int_as_float(0x7f800000);
+            const uint32_t last = beg + cnt - 1u;
+            float x[4], y[4], z[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+            {
+                x[c] = y[c] = z[c] = kInf;
+                if ((uint32_t)(c * kWave) < cnt) // wave-uniform
+                {
+                    const uint32_t j = min(beg + (uint32_t)(c * kWave + lane), last);
+                    x[c] = t.sx[j];
+                    y[c] = t.sy[j];
+                    z[c] = t.sz[j];
+                }
+            }
+            float s[4];
+            float smin = kInf;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+            {
+                const float d2 = sq_dist(bx, by, bz, x[c], y[c], z[c]);
+                s[c] = ((uint32_t)(c * kWave + lane) < cnt) ? d2 : kInf;
+                smin = fminf(smin, s[c]);
+            }
+            const float m = wave_min_nonneg(smin);
+            // candidates: every slot within 4 ulps of the minimum (a superset of the slots whose
+            // sqrt equals sqrt(m)); exactly one candidate is the common case
+            const float near = __uint_as_float(__float_as_uint(m) + 4u);
+            uint64_t h[4];
+            uint32_t total = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+            {
+                h[c] = __ballot(s[c] <= near);
+                total += (uint32_t)__builtin_popcountll(h[c]);
+            }
+            if (total != 1u)
+            {
+                // exact rule: first slot whose d2 rounds to the same sqrt as the minimum
+                const float hi = sq_ceiling_for_root(sqrtf(m));
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    h[c] = __ballot(s[c] <= hi);
+            }
+            uint32_t win = beg; // a NaN-poisoned bucket keeps slot 0, like the reference's scan
+            if (h[0])
+                win = beg + (uint32_t)__builtin_ctzll(h[0]);
+            else if (h[1])
+                win = beg + 64u + (uint32_t)__builtin_ctzll(h[1]);
+            else if (h[2])
+                win = beg + 128u + (uint32_t)__builtin_ctzll(h[2]);
+            else if (h[3])
+                win = beg + 192u + (uint32_t)__builtin_ctzll(h[3]);
+            m_out = m;
+            win_out = win;
+        }
+
+        __global__ void __launch_bounds__(kBlock, 5) // 5 workgroups per CU (LDS: 5 x 32 KiB)
+            nn_tile_kernel(DevTree t, const float* __restrict__ px, const float* __restrict__ py,
+                           const float* __restrict__ pz, float mux, float muy, float muz, uint32_t n,
+                           float* __restrict__ yx, float* __restrict__ yy, float* __restrict__ yz,
+                           uint32_t* __restrict__ row_out, float* __restrict__ dist_out,
+                           const uint32_t* __restrict__ perm, double* __restrict__ chunk_sums,
+                           uint32_t* __restrict__ queue, uint2* __restrict__ spill,
+                           uint32_t n_batches, uint32_t chunk_batches, uint32_t n_chunks)
+        {
+            __shared__ WaveLds s_w[kWavesPerBlock];
+
+            const int lane = threadIdx.x & (kWave - 1);
+            const int w = threadIdx.x >> 6;
+            WaveLds& L = s_w[w];
+            float* st_d = L.st_d + lane;
+            uint32_t* st_i = L.st_i + lane;
+            // this lane's column of the overflow stack: entry e at spill_col[e * spill_stride]
+            const size_t spill_stride = (size_t)gridDim.x * kBlock;
+            uint2* spill_col = spill + (size_t)blockIdx.x * kBlock + threadIdx.x;
+
+            // XCD group x owns chunks [x*per_group, (x+1)*per_group); its head is queue[x*32]
+            const uint32_t per_group = (n_chunks + 7u) >> 3;
+            uint32_t victim = 0;
+            uint32_t grp_x = blockIdx.x & 7u;
+            for (;;)
+            {
+                // ---- pull the next chunk ----
+                uint32_t chunk = 0;
+                bool have = false;
+                while (victim < 8u)
+                {
+                    const uint32_t lo = min(grp_x * per_group, n_chunks);
+                    const uint32_t hi = min(lo + per_group, n_chunks);
+                    uint32_t c = 0;
+                    if (lane == 0)
+                        c = __hip_atomic_fetch_add(queue + grp_x * 32u, 1u, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+                    c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+                    if (c < hi - lo)
+                    {
+                        chunk = lo + c;
+                        have = true;
+                        break;
+                    }
+                    victim += 1u; // this group is drained: steal from the next one
+                    grp_x = (grp_x + 1u) & 7u;
+                }
+                if (!have)
+                    break;
+                if (lane < kCovSums)
+                    L.sums[lane] = 0.0;
+                const uint32_t b_begin = chunk * chunk_batches;
+                const uint32_t b_end = min(b_begin + chunk_batches, n_batches);
+            for (uint32_t b = b_begin; b < b_end; ++b)
+            {
+                const uint32_t i = b * kWave + (uint32_t)lane;
+                const bool valid = i < n;
+                float qx = 0.f, qy = 0.f, qz = 0.f;
+                if (valid)
+                {
+                    // p_centered = p - mu_p (point-3d.cc:202-206)
+                    qx = __fsub_rn(px[i], mux);
+                    qy = __fsub_rn(py[i], muy);
+                    qz = __fsub_rn(pz[i], muz);
+                }
+                int node = t.root, prev = 0;
+                int mode = tDescend;
+                uint32_t sp = 0, ovf = 0;
+                uint32_t n_int = 0, n_pts = 0; // work counters of this query
+                float rd = 0.f;
+                uint32_t rid = 0;
+                uint32_t lbeg = 0, lcnt = 0;
+                if (!valid)
+                    mode = tDone;
+                else if (t.root < 0)
+                {
+                    const uint2 li = t.leaf_info[~t.root];
+                    lbeg = li.x;
+                    lcnt = li.y;
+                    n_pts = li.y;
+                    prev = t.root;
+                    node = -1;
+                    mode = tWaitLeaf;
+                }
+
+                for (;;)
+                {
+                    // ---- node phase: step every lane until it waits on a bucket or is done ----
+                    while (__ballot(mode <= tReturn) != 0ull)
+                    {
+                        if (mode <= tReturn)
+                        {
+                            const DevNode N = t.nodes[node];
+                            n_int += (mode == tDescend) ? 1u : 0u;
+                            const float d = sqrtf(sq_dist(qx, qy, qz, N.cx, N.cy, N.cz)); // :147
+                            const bool in_near = d < N.r;                                // :148
+                            const int nearc = in_near ? N.inside : N.outside;
+                            const int farc = in_near ? N.outside : N.inside;
+                            int go = nearc;
+                            bool down = true;
+                            if (mode == tReturn)
+                            {
+                                bool up;
+                                if (prev == nearc)
+                                {
+                                    // back from the near side (:152)
+                                    if (rd < fabsf(__fsub_rn(N.r, d)))
+                                        up = true;
+                                    else
+                                    {
+                                        if (sp < (uint32_t)kStackK)
+                                        {
+                                            st_d[sp * kWave] = rd;
+                                            st_i[sp * kWave] = rid;
+                                        }
+                                        else
+                                        {
+                                            spill_col[(sp - kStackK) * spill_stride] =
+                                                make_uint2(__float_as_uint(rd), rid);
+                                            ovf += 1u;
+                                        }
+                                        sp += 1u;
+                                        go = farc; // :160
+                                        up = false;
+                                    }
+                                }
+                                else
+                                {
+                                    // back from the far side (:163): far wins only if strictly closer
+                                    sp -= 1u;
+                                    float nd;
+                                    uint32_t ni;
+                                    if (sp < (uint32_t)kStackK)
+                                    {
+                                        nd = st_d[sp * kWave];
+                                        ni = st_i[sp * kWave];
+                                    }
+                                    else
+                                    {
+                                        const uint2 e = spill_col[(sp - kStackK) * spill_stride];
+                                        nd = __uint_as_float(e.x);
+                                        ni = e.y;
+                                    }
+                                    if (!(rd < nd))
+                                    {
+                                        rd = nd;
+                                        rid = ni;
+                                    }
+                                    up = true;
+                                }
+                                down = !up;
+                                if (up)
+                                {
+                                    if (d < rd) // :154 / :165 / :171 centre wins only if strictly closer
+                                    {
+                                        rd = d;
+                                        rid = t.n_slots + (uint32_t)node;
+                                    }
+                                    prev = node;
+                                    node = N.parent;
+                                    mode = node < 0 ? tDone : tReturn;
+                                }
+                            }
+                            if (down)
+                            {
+                                if (go >= 0)
+                                {
+                                    node = go;
+                                    mode = tDescend;
+                                }
+                                else
+                                {
+                                    const uint2 li = t.leaf_info[~go];
+                                    lbeg = li.x;
+                                    lcnt = li.y;
+                                    n_pts += li.y;
+                                    prev = go;
+                                    mode = tWaitLeaf;
+                                }
+                            }
+                        }
+                    }
+                    // ---- leaf phase: serve the waiting lanes bucket by bucket ----
+                    uint64_t pend = __ballot(mode == tWaitLeaf);
+                    if (pend == 0ull)
+                        break;
+                    while (pend)
+                    {
+                        const int l = (int)__builtin_ctzll(pend);
+                        const uint32_t beg = readlane_u(lbeg, l), cnt = readlane_u(lcnt, l);
+                        const bool member = (mode == tWaitLeaf) && (lbeg == beg);
+                        const uint64_t grp = __ballot(member);
+                        pend &= ~grp;
+                        if (__builtin_popcountll(grp) >= kTileMinGroup)
+                        {
+                            float m, m2;
+                            uint32_t idx;
+                            tile_scan(t, L, beg, cnt, grp, member, qx, qy, qz, lane, m, m2, idx);
+                            if (member)
+                            {
+                                const bool unique =
+                                    (__float_as_uint(m2) - __float_as_uint(m)) > 4u;
+                                rd = m;
+                                rid = beg + idx;
+                                mode = unique ? tServed : tWaitExact;
+                            }
+                        }
+                        else if (cnt <= (uint32_t)kImage)
+                        {
+                            uint64_t one = grp; // one or two lanes: the whole wave serves each
+                            while (one)
+                            {
+                                const int k = (int)__builtin_ctzll(one);
+                                one &= one - 1;
+                                float m;
+                                uint32_t win;
+                                coop_scan(t, readlane_f(qx, k), readlane_f(qy, k),
+                                          readlane_f(qz, k), beg, cnt, lane, m, win);
+                                if (lane == k)
+                                {
+                                    rd = m;
+                                    rid = win;
+                                    mode = tServed;
+                                }
+                            }
+                        }
+                        else if (member)
+                            mode = tWaitExact; // large bucket, small group: the looping exact scan
+                    }
+                    // ---- rare: the exact scan for lanes whose minimum is not isolated ----
+                    uint64_t ex = __ballot(mode == tWaitExact);
+                    while (ex)
+                    {
+                        const int l = (int)__builtin_ctzll(ex);
+                        ex &= ex - 1;
+                        const float bx = readlane_f(qx, l), by = readlane_f(qy, l),
+                                    bz = readlane_f(qz, l);
+                        const uint32_t beg = readlane_u(lbeg, l), cnt = readlane_u(lcnt, l);
+                        float r;
+                        uint32_t win;
+                        scan_bucket<0>(t, bx, by, bz, beg, cnt, lane, r, win);
+                        if (lane == l)
+                        {
+                            rd = r;
+                            rid = win;
+                            mode = node < 0 ? tDone : tReturn;
+                        }
+                    }
+                    if (mode == tServed)
+                    {
+                        rd = sqrtf(rd);
+                        mode = node < 0 ? tDone : tReturn;
+                    }
+                }
+
+                float ox = 0.f, oy = 0.f, oz = 0.f;
+                if (valid)
+                {
+                    uint32_t row;
+                    if (rid < t.n_slots)
+                    {
+                        ox = t.sx[rid];
+                        oy = t.sy[rid];
+                        oz = t.sz[rid];
+                        row = t.srow[rid];
+                    }
+                    else
+                    {
+                        const DevNode N = t.nodes[rid - t.n_slots];
+                        ox = N.cx;
+                        oy = N.cy;
+                        oz = N.cz;
+                        row = N.row;
+                    }
+                    if (yx)
+                    {
+                        yx[i] = ox;
+                        yy[i] = oy;
+                        yz[i] = oz;
+                    }
+                    if (row_out || dist_out)
+                    {
+                        const uint32_t o = perm ? perm[i] : i; // back to the caller's order
+                        if (row_out)
+                            row_out[o] = row;
+                        if (dist_out)
+                            dist_out[o] = rd;
+                    }
+                }
+                // fp32 products as find_covariance forms them (point-3d.cc:220-231), summed in
+                // fp64: lanes -> wave (fixed shuffle tree) -> this wave's running totals in LDS
+                {
+                    double v[kCovSums];
+                    v[0] = (double)__fmul_rn(qx, ox);
+                    v[1] = (double)__fmul_rn(qx, oy);
+                    v[2] = (double)__fmul_rn(qx, oz);
+                    v[3] = (double)__fmul_rn(qy, ox);
+                    v[4] = (double)__fmul_rn(qy, oy);
+                    v[5] = (double)__fmul_rn(qy, oz);
+                    v[6] = (double)__fmul_rn(qz, ox);
+                    v[7] = (double)__fmul_rn(qz, oy);
+                    v[8] = (double)__fmul_rn(qz, oz);
+                    v[9] = (double)n_int;
+                    v[10] = (double)n_pts;
+                    v[11] = (double)ovf;
+#pragma unroll
+                    for (int k = 0; k < kCovSums; ++k)
+                    {
+                        const double sk = wave_sum_f64(v[k]); // invalid lanes carry zeros
+                        if (lane == 0)
+                            L.sums[k] += sk;
+                    }
+                }
+            }
+                if (chunk_sums && lane < kCovSums)
+                    chunk_sums[(size_t)chunk * kCovSums + lane] = L.sums[lane];
+            }
+        }
+    } // namespace
+
+    hipError_t nn_tile_blocks_per_cu(int* out)
+    {
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, nn_tile_kernel, kBlock, 0);
+    }
+
+    uint32_t nn_tile_stack_entries() { return kStackK; }
+
+    hipError_t launch_nn_tile(const NnLaunch& a, const TileLaunch& q, hipStream_t s)
+    {
+        if (a.grid == 0 || q.chunk_batches == 0 || !q.queue)
+            return hipErrorInvalidValue;
+        if (a.height > (uint32_t)kStackK && !q.spill)
+            return hipErrorInvalidValue;
+        const uint32_t n_batches = (a.n + kWave - 1) / kWave;
+        const uint32_t n_chunks = (n_batches + q.chunk_batches - 1) / q.chunk_batches;
+        hipError_t e = hipMemsetAsync(q.queue, 0, kQueueWords * sizeof(uint32_t), s);
+        if (e != hipSuccess)
+            return e;
+        hipLaunchKernelGGL(nn_tile_kernel, dim3(a.grid), dim3(kBlock), 0, s, a.tree, a.px, a.py,
+                           a.pz, a.mu[0], a.mu[1], a.mu[2], a.n, a.yx, a.yy, a.yz, a.row_out,
+                           a.dist_out, a.perm, q.chunk_sums, q.queue, q.spill, n_batches,
+                           q.chunk_batches, n_chunks);
+        return hipGetLastError();
+    }
+} // namespace icp_dev
