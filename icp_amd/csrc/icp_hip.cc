@@ -138,6 +138,7 @@ struct icp_hip_ctx
     DevBuf<uint32_t> queue;
     DevBuf<double> chunk_sums;
     DevBuf<uint2> spill;
+    DevBuf<unsigned long long> stats; // ICP_HIP_TILE_STATS=1: event counters, printed per pass
     uint32_t chunk_batches = 1, n_chunks = 0, tile_grid_blocks = 8, spill_levels = 0;
     bool tile_ready = false;
 
@@ -268,6 +269,11 @@ namespace
         const uint32_t k = nn_tile_stack_entries();
         c->spill_levels = c->height > k ? c->height - k : 0;
         HIP_TRY(c, c->queue.alloc(kQueueWords));
+        {
+            const char* env = std::getenv("ICP_HIP_TILE_STATS");
+            if (env && env[0] == '1')
+                HIP_TRY(c, c->stats.alloc(8));
+        }
         HIP_TRY(c, c->chunk_sums.alloc((size_t)c->n_chunks * kCovSums));
         HIP_TRY(c, c->spill.alloc((size_t)c->spill_levels * c->tile_grid_blocks * 256));
         c->tile_ready = true;
@@ -291,10 +297,23 @@ namespace
         else
         {
             a.grid = c->tile_grid_blocks;
-            TileLaunch q{c->chunk_batches, c->chunk_sums.p, c->queue.p, c->spill.p};
+            TileLaunch q{c->chunk_batches, c->chunk_sums.p, c->queue.p, c->spill.p, c->stats.p};
+            if (c->stats.p)
+                HIP_TRY(c, hipMemsetAsync(c->stats.p, 0, 8 * sizeof(unsigned long long), c->stream));
             HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
             HIP_TRY(c, launch_nn_tile(a, q, c->stream));
             HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+            if (c->stats.p)
+            {
+                unsigned long long h[8];
+                HIP_TRY(c, hipMemcpyAsync(h, c->stats.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                std::fprintf(stderr,
+                             "[tile stats] batches %llu node_iters %llu node_lane_steps %llu "
+                             "leaf_phases %llu tile_scans %llu tile_lanes %llu coop_scans %llu "
+                             "exact_scans %llu\n",
+                             h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+            }
             // chunk sums -> <= 1024 partial rows -> the twelve sums, both in a fixed order
             uint32_t g1 = (c->n_chunks + 63) / 64;
             g1 = g1 > 1024 ? 1024 : g1;
@@ -535,6 +554,7 @@ extern "C"
         c->queue.release();
         c->chunk_sums.release();
         c->spill.release();
+        c->stats.release();
         c->partials.release();
         c->sums.release();
         if (c->h_sums)

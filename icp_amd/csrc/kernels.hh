@@ -72,6 +72,7 @@ namespace icp_dev
         double* chunk_sums;     // [n_chunks][kCovSums] or null
         uint32_t* queue;        // kQueueWords words, zeroed by the launch
         uint2* spill;           // [max(0, height - stack entries)][grid * 256] or null
+        unsigned long long* stats; // 8 event counters of the diagnostic build, or null
     };
     hipError_t launch_nn_tile(const NnLaunch& a, const TileLaunch& q, hipStream_t s);
     hipError_t nn_tile_blocks_per_cu(int* out);

@@ -43,6 +43,7 @@ namespace icp_dev
     {
         constexpr int kStackK = 7;  // LDS stack entries per lane
         constexpr int kImage = 256; // bucket slots staged per window
+        constexpr int kGroups = kImage / 4; // float4 groups of the image; group kGroups is +inf
         constexpr int kTileMinGroup = 3; // fewer lanes on a bucket: whole-wave scan per lane
 
         enum : int
@@ -59,7 +60,7 @@ namespace icp_dev
         {
             float st_d[kStackK * kWave];
             uint32_t st_i[kStackK * kWave];
-            float bx[kImage], by[kImage], bz[kImage];
+            float bx[kImage + 4], by[kImage + 4], bz[kImage + 4]; // + the all-inf float4 group
             float4 qb[kWave]; // queries by rank in the group, then their results
             double sums[kCovSums + 4]; // this wave's running totals (fixed summation order)
         };
@@ -73,28 +74,32 @@ namespace icp_dev
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
 
-        __device__ __forceinline__ void track(float d2, uint32_t k, float& m, float& m2,
-                                              uint32_t& idx)
+        // second smallest (with multiplicity) and smallest of a stream: m <= m2 always
+        __device__ __forceinline__ void track2(float v, float& m, float& m2)
         {
-            idx = (d2 < m) ? k : idx;
-            m2 = __builtin_amdgcn_fmed3f(m, m2, d2); // m <= m2: second smallest of {m, m2, d2}
-            m = fminf(m, d2);
+            m2 = __builtin_amdgcn_fmed3f(m, m2, v);
+            m = fminf(m, v);
         }
 
-        // Tile scan of bucket [beg, beg+cnt) for the lanes in `grp` (all of them wait on it).
-        // On return every member lane has (m, m2, slot-in-bucket of m).
+        // Tile scan of bucket [beg, beg+cnt) for the g lanes in `grp` (all of them wait on it).
+        // The 64 lanes form P = 64/g parts of g lanes; lane (part p, slot s) scans the float4
+        // groups p, p+P, p+2P, .. of the staged image for the query of rank s.  Inside the loop
+        // only the minimum of each float4 group is tracked (its step, the smallest and the second
+        // smallest group minimum); the winning group is re-read once at the end to find the slot
+        // and the second smallest distance inside it.  On return every member lane has
+        // (m, m2, slot-in-bucket of m) with m2 = second smallest d2 counted with multiplicity.
         __device__ __forceinline__ void tile_scan(const DevTree& t, WaveLds& L, uint32_t beg,
                                                   uint32_t cnt, uint64_t grp, bool member, float qx,
                                                   float qy, float qz, int lane, float& out_m,
                                                   float& out_m2, uint32_t& out_idx)
         {
             const float kInf = __int_as_float(0x7f800000);
-            const uint32_t g = (uint32_t)__builtin_popcountll(grp);
-            // gp = pow2 >= g, lg = log2(gp)
-            const uint32_t lg = (g <= 1u) ? 0u : (32u - (uint32_t)__builtin_clz(g - 1u));
-            const uint32_t gp = 1u << lg;
-            const uint32_t P = 64u >> lg;
-            const uint32_t part = (uint32_t)lane >> lg;
+            const uint32_t g = (uint32_t)__builtin_popcountll(grp); // 1..64
+            const uint32_t P = 64u / g;
+            // lane / g for lane < 64 (exact for every g in 1..64)
+            const uint32_t part = ((uint32_t)lane * (65536u / g + 1u)) >> 16;
+            const uint32_t slot = (uint32_t)lane - part * g;
+            const bool idle = part >= P; // lanes past the last whole part read the +inf group
 
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi(
                 (uint32_t)(grp >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)grp, 0u));
@@ -127,39 +132,66 @@ namespace icp_dev
                     *reinterpret_cast<float4*>(L.bz + s0) = vz;
                 }
                 wave_lds_fence();
-                const float4 q = L.qb[lane & (gp - 1u)];
-                // part p scans slots [p*len, (p+1)*len) of the window; P*len <= 256
-                const uint32_t len = (((cw + P - 1u) >> (6u - lg)) + 3u) & ~3u;
-                const uint32_t pbase = part * len;
-                const float* bx = L.bx + pbase;
-                const float* by = L.by + pbase;
-                const float* bz = L.bz + pbase;
+                const float4 q = L.qb[slot];
+                const uint32_t n4 = (cw + 3u) >> 2;           // float4 groups in the window
+                const uint32_t steps = (n4 + P - 1u) / P;     // wave-uniform
+                uint32_t gi = idle ? (uint32_t)kGroups : part; // group of this lane at step 0
                 const float m_before = m;
                 uint32_t kbest = 0;
 #pragma nounroll
-                for (uint32_t k = 0; k < len; k += 4)
+                for (uint32_t k = 0; k < steps; ++k)
                 {
-                    const float4 X = *reinterpret_cast<const float4*>(bx + k);
-                    const float4 Y = *reinterpret_cast<const float4*>(by + k);
-                    const float4 Z = *reinterpret_cast<const float4*>(bz + k);
-                    track(sq_dist(q.x, q.y, q.z, X.x, Y.x, Z.x), k, m, m2, kbest);
-                    track(sq_dist(q.x, q.y, q.z, X.y, Y.y, Z.y), k + 1u, m, m2, kbest);
-                    track(sq_dist(q.x, q.y, q.z, X.z, Y.z, Z.z), k + 2u, m, m2, kbest);
-                    track(sq_dist(q.x, q.y, q.z, X.w, Y.w, Z.w), k + 3u, m, m2, kbest);
+                    const uint32_t gc = min(gi, (uint32_t)kGroups); // group 64 is all +inf
+                    const float4 X = *reinterpret_cast<const float4*>(L.bx + 4u * gc);
+                    const float4 Y = *reinterpret_cast<const float4*>(L.by + 4u * gc);
+                    const float4 Z = *reinterpret_cast<const float4*>(L.bz + 4u * gc);
+                    const float d0 = sq_dist(q.x, q.y, q.z, X.x, Y.x, Z.x);
+                    const float d1 = sq_dist(q.x, q.y, q.z, X.y, Y.y, Z.y);
+                    const float d2 = sq_dist(q.x, q.y, q.z, X.z, Y.z, Z.z);
+                    const float d3 = sq_dist(q.x, q.y, q.z, X.w, Y.w, Z.w);
+                    const float gm = fminf(fminf(fminf(d0, d1), d2), d3);
+                    kbest = (gm < m) ? k : kbest;
+                    track2(gm, m, m2);
+                    gi += P;
                 }
-                idx = (m < m_before) ? (w0 + pbase + kbest) : idx;
+                if (m < m_before)
+                {
+                    // the winning group again: slot of m and the runner-up inside the group
+                    const uint32_t gw = part + P * kbest;
+                    const float4 X = *reinterpret_cast<const float4*>(L.bx + 4u * gw);
+                    const float4 Y = *reinterpret_cast<const float4*>(L.by + 4u * gw);
+                    const float4 Z = *reinterpret_cast<const float4*>(L.bz + 4u * gw);
+                    const float d0 = sq_dist(q.x, q.y, q.z, X.x, Y.x, Z.x);
+                    const float d1 = sq_dist(q.x, q.y, q.z, X.y, Y.y, Z.y);
+                    const float d2 = sq_dist(q.x, q.y, q.z, X.z, Y.z, Z.z);
+                    const float d3 = sq_dist(q.x, q.y, q.z, X.w, Y.w, Z.w);
+                    float a = kInf, b2 = kInf;
+                    track2(d0, a, b2);
+                    track2(d1, a, b2);
+                    track2(d2, a, b2);
+                    track2(d3, a, b2);
+                    const uint32_t c = (d0 == m) ? 0u : (d1 == m) ? 1u : (d2 == m) ? 2u : 3u;
+                    idx = w0 + 4u * gw + c;
+                    m2 = fminf(m2, b2);
+                }
                 wave_lds_fence(); // the next window overwrites the image
             }
-            // ---- fold the parts: lane l takes lane l + D, D = gp, 2gp, .. 32 ----
+            // ---- fold the parts: part p takes part p + half, halving until one part is left ----
 #pragma nounroll
-            for (uint32_t D = gp; D < 64u; D <<= 1)
+            for (uint32_t h = P; h > 1u;)
             {
-                const float mb = __shfl_down(m, D, kWave);
-                const float m2b = __shfl_down(m2, D, kWave);
-                const uint32_t ib = __shfl_down(idx, D, kWave);
-                idx = (mb < m) ? ib : idx;
-                m2 = fminf(fminf(m2, m2b), fmaxf(m, mb));
-                m = fminf(m, mb);
+                const uint32_t half = (h + 1u) >> 1;
+                const int src = lane + (int)(half * g);
+                const float mb = __shfl(m, src, kWave);
+                const float m2b = __shfl(m2, src, kWave);
+                const uint32_t ib = __shfl(idx, src, kWave);
+                if (part + half < h)
+                {
+                    idx = (mb < m) ? ib : idx;
+                    m2 = fminf(fminf(m2, m2b), fmaxf(m, mb));
+                    m = fminf(m, mb);
+                }
+                h = half;
             }
             if ((uint32_t)lane < g)
                 L.qb[lane] = make_float4(m, m2, __uint_as_float(idx), 0.f);
@@ -170,7 +202,6 @@ namespace icp_dev
             out_idx = __float_as_uint(r.z);
             wave_lds_fence();
         }
-
 
         // Whole-wave scan of one bucket of <= 256 slots for ONE query (arguments wave-uniform):
         // the cheaper form when only one or two lanes wait on the bucket.  All chunk loads are
@@ -237,6 +268,7 @@ namespace icp_dev
             win_out = win;
         }
 
+        template <bool STATS>
         __global__ void __launch_bounds__(kBlock, 5) // 5 workgroups per CU (LDS: 5 x 32 KiB)
             nn_tile_kernel(DevTree t, const float* __restrict__ px, const float* __restrict__ py,
                            const float* __restrict__ pz, float mux, float muy, float muz, uint32_t n,
@@ -244,15 +276,25 @@ namespace icp_dev
                            uint32_t* __restrict__ row_out, float* __restrict__ dist_out,
                            const uint32_t* __restrict__ perm, double* __restrict__ chunk_sums,
                            uint32_t* __restrict__ queue, uint2* __restrict__ spill,
-                           uint32_t n_batches, uint32_t chunk_batches, uint32_t n_chunks)
+                           uint32_t n_batches, uint32_t chunk_batches, uint32_t n_chunks,
+                           unsigned long long* __restrict__ stats)
         {
             __shared__ WaveLds s_w[kWavesPerBlock];
+            // wave-level event counts of the diagnostic build (ICP_HIP_TILE_STATS=1)
+            uint32_t st_node = 0, st_tile = 0, st_tile_g = 0, st_tile_len = 0, st_coop = 0,
+                     st_exact = 0, st_leafph = 0, st_batch = 0, st_node_lanes = 0;
 
             const int lane = threadIdx.x & (kWave - 1);
             const int w = threadIdx.x >> 6;
             WaveLds& L = s_w[w];
             float* st_d = L.st_d + lane;
             uint32_t* st_i = L.st_i + lane;
+            if (lane < 4)
+            {
+                L.bx[kImage + lane] = __int_as_float(0x7f800000);
+                L.by[kImage + lane] = 0.f;
+                L.bz[kImage + lane] = 0.f;
+            }
             // this lane's column of the overflow stack: entry e at spill_col[e * spill_stride]
             const size_t spill_stride = (size_t)gridDim.x * kBlock;
             uint2* spill_col = spill + (size_t)blockIdx.x * kBlock + threadIdx.x;
@@ -292,6 +334,8 @@ namespace icp_dev
                 const uint32_t b_end = min(b_begin + chunk_batches, n_batches);
             for (uint32_t b = b_begin; b < b_end; ++b)
             {
+                if (STATS)
+                    st_batch += 1u;
                 const uint32_t i = b * kWave + (uint32_t)lane;
                 const bool valid = i < n;
                 float qx = 0.f, qy = 0.f, qz = 0.f;
@@ -325,8 +369,16 @@ namespace icp_dev
                 for (;;)
                 {
                     // ---- node phase: step every lane until it waits on a bucket or is done ----
-                    while (__ballot(mode <= tReturn) != 0ull)
+                    for (;;)
                     {
+                        const uint64_t stepping = __ballot(mode <= tReturn);
+                        if (stepping == 0ull)
+                            break;
+                        if (STATS)
+                        {
+                            st_node += 1u;
+                            st_node_lanes += (uint32_t)__builtin_popcountll(stepping);
+                        }
                         if (mode <= tReturn)
                         {
                             const DevNode N = t.nodes[node];
@@ -423,6 +475,8 @@ namespace icp_dev
                     uint64_t pend = __ballot(mode == tWaitLeaf);
                     if (pend == 0ull)
                         break;
+                    if (STATS)
+                        st_leafph += 1u;
                     while (pend)
                     {
                         const int l = (int)__builtin_ctzll(pend);
@@ -435,6 +489,11 @@ namespace icp_dev
                             float m, m2;
                             uint32_t idx;
                             tile_scan(t, L, beg, cnt, grp, member, qx, qy, qz, lane, m, m2, idx);
+                            if (STATS)
+                            {
+                                st_tile += 1u;
+                                st_tile_g += (uint32_t)__builtin_popcountll(grp);
+                            }
                             if (member)
                             {
                                 const bool unique =
@@ -451,6 +510,8 @@ namespace icp_dev
                             {
                                 const int k = (int)__builtin_ctzll(one);
                                 one &= one - 1;
+                                if (STATS)
+                                    st_coop += 1u;
                                 float m;
                                 uint32_t win;
                                 coop_scan(t, readlane_f(qx, k), readlane_f(qy, k),
@@ -472,6 +533,8 @@ namespace icp_dev
                     {
                         const int l = (int)__builtin_ctzll(ex);
                         ex &= ex - 1;
+                        if (STATS)
+                            st_exact += 1u;
                         const float bx = readlane_f(qx, l), by = readlane_f(qy, l),
                                     bz = readlane_f(qz, l);
                         const uint32_t beg = readlane_u(lbeg, l), cnt = readlane_u(lcnt, l);
@@ -554,12 +617,24 @@ namespace icp_dev
                 if (chunk_sums && lane < kCovSums)
                     chunk_sums[(size_t)chunk * kCovSums + lane] = L.sums[lane];
             }
+            if (STATS && lane == 0)
+            {
+                atomicAdd(stats + 0, (unsigned long long)st_batch);
+                atomicAdd(stats + 1, (unsigned long long)st_node);
+                atomicAdd(stats + 2, (unsigned long long)st_node_lanes);
+                atomicAdd(stats + 3, (unsigned long long)st_leafph);
+                atomicAdd(stats + 4, (unsigned long long)st_tile);
+                atomicAdd(stats + 5, (unsigned long long)st_tile_g);
+                atomicAdd(stats + 6, (unsigned long long)st_coop);
+                atomicAdd(stats + 7, (unsigned long long)st_exact);
+                (void)st_tile_len;
+            }
         }
     } // namespace
 
     hipError_t nn_tile_blocks_per_cu(int* out)
     {
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, nn_tile_kernel, kBlock, 0);
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, nn_tile_kernel<false>, kBlock, 0);
     }
 
     uint32_t nn_tile_stack_entries() { return kStackK; }
@@ -575,10 +650,16 @@ namespace icp_dev
         hipError_t e = hipMemsetAsync(q.queue, 0, kQueueWords * sizeof(uint32_t), s);
         if (e != hipSuccess)
             return e;
-        hipLaunchKernelGGL(nn_tile_kernel, dim3(a.grid), dim3(kBlock), 0, s, a.tree, a.px, a.py,
-                           a.pz, a.mu[0], a.mu[1], a.mu[2], a.n, a.yx, a.yy, a.yz, a.row_out,
-                           a.dist_out, a.perm, q.chunk_sums, q.queue, q.spill, n_batches,
-                           q.chunk_batches, n_chunks);
+        if (q.stats)
+            hipLaunchKernelGGL(nn_tile_kernel<true>, dim3(a.grid), dim3(kBlock), 0, s, a.tree, a.px,
+                               a.py, a.pz, a.mu[0], a.mu[1], a.mu[2], a.n, a.yx, a.yy, a.yz,
+                               a.row_out, a.dist_out, a.perm, q.chunk_sums, q.queue, q.spill,
+                               n_batches, q.chunk_batches, n_chunks, q.stats);
+        else
+            hipLaunchKernelGGL(nn_tile_kernel<false>, dim3(a.grid), dim3(kBlock), 0, s, a.tree, a.px,
+                               a.py, a.pz, a.mu[0], a.mu[1], a.mu[2], a.n, a.yx, a.yy, a.yz,
+                               a.row_out, a.dist_out, a.perm, q.chunk_sums, q.queue, q.spill,
+                               n_batches, q.chunk_batches, n_chunks, nullptr);
         return hipGetLastError();
     }
 } // namespace icp_dev

@@ -34,7 +34,7 @@ def load(path, counter):
 f, w = load(a.fetch_csv, "FETCH_SIZE"), load(a.write_csv, "WRITE_SIZE")
 cal = [k for k in f if "sum_points_kernel" in k][0]
 factor = 12.0 * a.points / (sum(f[cal]) / len(f[cal]))
-nn = [k for k in f if "nn_cov_kernel" in k][0]
+nn = [k for k in f if "nn_tile_kernel" in k or "nn_cov_kernel" in k][0]
 fetch = [v * factor for v in f[nn]]
 write = w[nn]
 if a.steps:

@@ -26,7 +26,7 @@ print(f"{'kernel':60s} {'calls':>6s} {'total_ms':>12s} {'avg_ms':>10s} {'share':
 for name, v in sorted(per.items(), key=lambda kv: -sum(d for _, d in kv[1])):
     t = sum(d for _, d in v)
     print(f"{name[:60]:60s} {len(v):6d} {t/1e6:12.3f} {t/len(v)/1e6:10.4f} {100*t/total:6.2f}%  {meta[name]}")
-nn = [k for k in per if "nn_cov_kernel" in k]
+nn = [k for k in per if "nn_tile_kernel" in k or "nn_cov_kernel" in k]
 for k in nn:
     v = sorted(per[k])[-a.steps:]
     avg = sum(d for _, d in v) / len(v) / 1e6
