@@ -12,6 +12,7 @@
 #include <limits>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "host_common.hh"
@@ -119,7 +120,7 @@ struct icp_hip_ctx
     DevBuf<DevNode> nodes;
     DevBuf<uint2> leaf_info;
     DevBuf<float> sx, sy, sz;
-    DevBuf<uint32_t> srow;
+    DevBuf<uint32_t> srow, nrow;
 
     // query shard
     uint64_t n_local = 0, n_total = 0;
@@ -141,6 +142,7 @@ struct icp_hip_ctx
     DevBuf<unsigned long long> stats; // ICP_HIP_TILE_STATS=1: event counters, printed per pass
     uint32_t chunk_batches = 1, n_chunks = 0, tile_grid_blocks = 8, spill_levels = 0;
     bool tile_ready = false;
+    uint32_t tile_cut = 1; // ICP_HIP_TILE_CUT overrides (0 = run the node phase to the end)
 
     icp_hip_allreduce_fn allreduce = nullptr;
     void* allreduce_user = nullptr;
@@ -297,7 +299,8 @@ namespace
         else
         {
             a.grid = c->tile_grid_blocks;
-            TileLaunch q{c->chunk_batches, c->chunk_sums.p, c->queue.p, c->spill.p, c->stats.p};
+            TileLaunch q{c->chunk_batches, c->chunk_sums.p, c->queue.p, c->spill.p, c->stats.p,
+                         c->tile_cut};
             if (c->stats.p)
                 HIP_TRY(c, hipMemsetAsync(c->stats.p, 0, 8 * sizeof(unsigned long long), c->stream));
             HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
@@ -390,10 +393,44 @@ namespace
                 lo[k] = 0.f;
         }
         HIP_TRY(c, launch_morton(c->aos.p, n, lo, scale, keys.p, idx.p, c->stream));
-        HIP_TRY(c, sort_pairs_u32(keys.p, keys2.p, idx.p, c->perm.p, n, c->stream));
+        HIP_TRY(c, sort_pairs_u32(keys.p, keys2.p, idx.p, c->perm.p, n, 30u, c->stream));
         HIP_TRY(c, launch_gather_soa(c->aos.p, c->perm.p, n, c->px.p, c->py.p, c->pz.p, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->sorted = true;
+        const char* env = std::getenv("ICP_HIP_LEAF_ORDER");
+        if (c->has_tree && c->tree.root >= 0 && !(env && env[0] == '0'))
+        {
+            // second stable sort: leaf reached by the near-only descent of p - mean(p of this shard)
+            HIP_TRY(c, launch_sum_points(c->px.p, c->py.p, c->pz.p, n, grid, c->partials.p,
+                                         c->stream));
+            HIP_TRY(c, launch_reduce_partials(c->partials.p, grid, kApplySums, c->sums.p, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(c->h_sums, c->sums.p, sizeof(double) * kApplySums,
+                                      hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            const float mu[3] = {(float)(c->h_sums[1] / n), (float)(c->h_sums[2] / n),
+                                 (float)(c->h_sums[3] / n)};
+            uint32_t bits = 1;
+            while (bits < 32 && (1ull << bits) < c->leaf_info.count)
+                ++bits;
+            HIP_TRY(c, launch_leaf_keys(c->tree, c->px.p, c->py.p, c->pz.p, mu, n, keys.p, idx.p,
+                                        c->stream));
+            DevBuf<uint32_t> order;
+            struct Free
+            {
+                DevBuf<uint32_t>& b;
+                ~Free() { b.release(); }
+            } free_order{order};
+            HIP_TRY(c, order.alloc(n));
+            HIP_TRY(c, sort_pairs_u32(keys.p, keys2.p, idx.p, order.p, n, bits, c->stream));
+            // the matched-point arrays are free until the first pass: permute into them and swap
+            HIP_TRY(c, launch_permute_soa(c->px.p, c->py.p, c->pz.p, c->perm.p, order.p, n, c->yx.p,
+                                          c->yy.p, c->yz.p, idx.p, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            std::swap(c->px, c->yx);
+            std::swap(c->py, c->yy);
+            std::swap(c->pz, c->yz);
+            std::swap(c->perm, idx); // `idx` (old perm) is released by the cleanup guard
+        }
         return ICP_HIP_OK;
     }
 } // namespace
@@ -521,6 +558,9 @@ extern "C"
             c->tile_blocks = (uint32_t)blocks;
             const char* env = std::getenv("ICP_HIP_NN_KERNEL");
             c->force_deep = env && std::strcmp(env, "deep") == 0;
+            const char* cut = std::getenv("ICP_HIP_TILE_CUT");
+            if (cut)
+                c->tile_cut = (uint32_t)std::atoi(cut);
         }
         *out = c;
         return ICP_HIP_OK;
@@ -541,6 +581,7 @@ extern "C"
         c->sy.release();
         c->sz.release();
         c->srow.release();
+        c->nrow.release();
         c->px.release();
         c->py.release();
         c->pz.release();
@@ -591,13 +632,11 @@ extern "C"
         // staging for the SoA node arrays, packed into 32-byte records on the device
         DevBuf<float> f4[4];
         DevBuf<int32_t> i3[3];
-        DevBuf<uint32_t> nrow;
         auto cleanup = [&]() {
             for (auto& b : f4)
                 b.release();
             for (auto& b : i3)
                 b.release();
-            nrow.release();
         };
         hipError_t e = hipSuccess;
         auto up = [&](auto& buf, const auto* src, size_t n) -> bool {
@@ -612,10 +651,10 @@ extern "C"
         ok = ok && up(f4[0], t->node_cx, nn) && up(f4[1], t->node_cy, nn) &&
              up(f4[2], t->node_cz, nn) && up(f4[3], t->node_radius, nn) &&
              up(i3[0], t->node_inside, nn) && up(i3[1], t->node_outside, nn) &&
-             up(i3[2], t->node_parent, nn) && up(nrow, t->node_row, nn);
+             up(i3[2], t->node_parent, nn) && up(c->nrow, t->node_row, nn);
         if (ok && nn)
             ok = (e = launch_pack_nodes(f4[0].p, f4[1].p, f4[2].p, f4[3].p, i3[0].p, i3[1].p,
-                                        i3[2].p, nrow.p, (uint32_t)nn, c->nodes.p, c->stream)) ==
+                                        i3[2].p, (uint32_t)nn, c->nodes.p, c->stream)) ==
                  hipSuccess;
         // leaves {begin,count}
         std::vector<uint2> li(nl);
@@ -648,6 +687,7 @@ extern "C"
         c->tree.sy = c->sy.p;
         c->tree.sz = c->sz.p;
         c->tree.srow = c->srow.p;
+        c->tree.nrow = c->nrow.p;
         c->tree.n_slots = (uint32_t)ns;
         c->tree.n_nodes = (uint32_t)nn;
         c->tree.root = t->root;

@@ -13,7 +13,8 @@ namespace icp_dev
     {
         float cx, cy, cz, r;
         int32_t inside, outside, parent; // child codes: >= 0 internal index, < 0 ~leaf
-        uint32_t row;
+        float thr; // smallest float whose correctly rounded sqrt is >= r:
+                   // sqrtf(d2) < r  <=>  d2 < thr, so a descent needs no sqrt (vp-tree.cc:148)
     };
 
     struct DevTree
@@ -24,6 +25,7 @@ namespace icp_dev
         const float* sy;
         const float* sz;
         const uint32_t* srow;
+        const uint32_t* nrow; // row of each internal node's centre
         uint32_t n_slots;
         uint32_t n_nodes;
         int32_t root;
@@ -73,6 +75,7 @@ namespace icp_dev
         uint32_t* queue;        // kQueueWords words, zeroed by the launch
         uint2* spill;           // [max(0, height - stack entries)][grid * 256] or null
         unsigned long long* stats; // 8 event counters of the diagnostic build, or null
+        uint32_t cut; // leave the node phase when waiting lanes >= cut x stepping lanes (0: never)
     };
     hipError_t launch_nn_tile(const NnLaunch& a, const TileLaunch& q, hipStream_t s);
     hipError_t nn_tile_blocks_per_cu(int* out);
@@ -97,7 +100,13 @@ namespace icp_dev
     hipError_t launch_morton(const float* aos, uint32_t n, const float lo[3], const float scale[3],
                              uint32_t* keys, uint32_t* idx, hipStream_t s);
     hipError_t sort_pairs_u32(const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* idx_in,
-                              uint32_t* idx_out, uint32_t n, hipStream_t s);
+                              uint32_t* idx_out, uint32_t n, uint32_t bits, hipStream_t s);
+    hipError_t launch_leaf_keys(const DevTree& t, const float* px, const float* py, const float* pz,
+                                const float mu[3], uint32_t n, uint32_t* keys, uint32_t* idx,
+                                hipStream_t s);
+    hipError_t launch_permute_soa(const float* x, const float* y, const float* z,
+                                  const uint32_t* perm, const uint32_t* order, uint32_t n, float* ox,
+                                  float* oy, float* oz, uint32_t* operm, hipStream_t s);
     hipError_t launch_gather_soa(const float* aos, const uint32_t* perm, uint32_t n, float* x,
                                  float* y, float* z, hipStream_t s);
     hipError_t launch_scatter_aos(const float* x, const float* y, const float* z,
@@ -105,6 +114,5 @@ namespace icp_dev
 
     hipError_t launch_pack_nodes(const float* cx, const float* cy, const float* cz, const float* r,
                                  const int32_t* inside, const int32_t* outside,
-                                 const int32_t* parent, const uint32_t* row, uint32_t n,
-                                 DevNode* out, hipStream_t s);
+                                 const int32_t* parent, uint32_t n, DevNode* out, hipStream_t s);
 } // namespace icp_dev

@@ -211,7 +211,7 @@ namespace icp_dev
                     ox = N.cx;
                     oy = N.cy;
                     oz = N.cz;
-                    row = N.row;
+                    row = t.nrow[rid - t.n_slots];
                 }
                 if (yx)
                 {
@@ -376,7 +376,7 @@ namespace icp_dev
     __global__ void __launch_bounds__(kBlock)
         pack_nodes_kernel(const float* cx, const float* cy, const float* cz, const float* r,
                           const int32_t* inside, const int32_t* outside, const int32_t* parent,
-                          const uint32_t* row, uint32_t n, DevNode* __restrict__ out)
+                          uint32_t n, DevNode* __restrict__ out)
     {
         for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
         {
@@ -388,7 +388,17 @@ namespace icp_dev
             N.inside = inside[i];
             N.outside = outside[i];
             N.parent = parent[i];
-            N.row = row[i];
+            // thr = min { s : sqrtf(s) >= r }, found by stepping from r*r (a few ulps at most)
+            float th = 0.f;
+            if (N.r > 0.f)
+            {
+                th = __fmul_rn(N.r, N.r);
+                while (th > 0.f && sqrtf(__uint_as_float(__float_as_uint(th) - 1u)) >= N.r)
+                    th = __uint_as_float(__float_as_uint(th) - 1u);
+                while (sqrtf(th) < N.r)
+                    th = __uint_as_float(__float_as_uint(th) + 1u);
+            }
+            N.thr = th;
             out[i] = N;
         }
     }
@@ -496,13 +506,12 @@ namespace icp_dev
 
     hipError_t launch_pack_nodes(const float* cx, const float* cy, const float* cz, const float* r,
                                  const int32_t* inside, const int32_t* outside,
-                                 const int32_t* parent, const uint32_t* row, uint32_t n,
-                                 DevNode* out, hipStream_t s)
+                                 const int32_t* parent, uint32_t n, DevNode* out, hipStream_t s)
     {
         if (n == 0)
             return hipSuccess;
         hipLaunchKernelGGL(pack_nodes_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, s, cx, cy, cz,
-                           r, inside, outside, parent, row, n, out);
+                           r, inside, outside, parent, n, out);
         return hipGetLastError();
     }
 } // namespace icp_dev

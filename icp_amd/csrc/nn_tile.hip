@@ -277,7 +277,7 @@ namespace icp_dev
                            const uint32_t* __restrict__ perm, double* __restrict__ chunk_sums,
                            uint32_t* __restrict__ queue, uint2* __restrict__ spill,
                            uint32_t n_batches, uint32_t chunk_batches, uint32_t n_chunks,
-                           unsigned long long* __restrict__ stats)
+                           uint32_t cut, unsigned long long* __restrict__ stats)
         {
             __shared__ WaveLds s_w[kWavesPerBlock];
             // wave-level event counts of the diagnostic build (ICP_HIP_TILE_STATS=1)
@@ -374,6 +374,13 @@ namespace icp_dev
                         const uint64_t stepping = __ballot(mode <= tReturn);
                         if (stepping == 0ull)
                             break;
+                        // a few stragglers deep in far subtrees must not hold up the lanes that
+                        // already wait on a bucket: serve those first once they outnumber the
+                        // stepping lanes `cut` to one
+                        if (cut != 0u &&
+                            (uint32_t)__builtin_popcountll(stepping) * cut <=
+                                (uint32_t)__builtin_popcountll(__ballot(mode == tWaitLeaf)))
+                            break;
                         if (STATS)
                         {
                             st_node += 1u;
@@ -383,14 +390,15 @@ namespace icp_dev
                         {
                             const DevNode N = t.nodes[node];
                             n_int += (mode == tDescend) ? 1u : 0u;
-                            const float d = sqrtf(sq_dist(qx, qy, qz, N.cx, N.cy, N.cz)); // :147
-                            const bool in_near = d < N.r;                                // :148
+                            const float d2 = sq_dist(qx, qy, qz, N.cx, N.cy, N.cz);
+                            const bool in_near = d2 < N.thr; // sqrtf(d2) < N.r (:147-148)
                             const int nearc = in_near ? N.inside : N.outside;
                             const int farc = in_near ? N.outside : N.inside;
                             int go = nearc;
                             bool down = true;
                             if (mode == tReturn)
                             {
+                                const float d = sqrtf(d2); // only the way up compares distances
                                 bool up;
                                 if (prev == nearc)
                                 {
@@ -572,7 +580,7 @@ namespace icp_dev
                         ox = N.cx;
                         oy = N.cy;
                         oz = N.cz;
-                        row = N.row;
+                        row = t.nrow[rid - t.n_slots];
                     }
                     if (yx)
                     {
@@ -654,12 +662,12 @@ namespace icp_dev
             hipLaunchKernelGGL(nn_tile_kernel<true>, dim3(a.grid), dim3(kBlock), 0, s, a.tree, a.px,
                                a.py, a.pz, a.mu[0], a.mu[1], a.mu[2], a.n, a.yx, a.yy, a.yz,
                                a.row_out, a.dist_out, a.perm, q.chunk_sums, q.queue, q.spill,
-                               n_batches, q.chunk_batches, n_chunks, q.stats);
+                               n_batches, q.chunk_batches, n_chunks, q.cut, q.stats);
         else
             hipLaunchKernelGGL(nn_tile_kernel<false>, dim3(a.grid), dim3(kBlock), 0, s, a.tree, a.px,
                                a.py, a.pz, a.mu[0], a.mu[1], a.mu[2], a.n, a.yx, a.yy, a.yz,
                                a.row_out, a.dist_out, a.perm, q.chunk_sums, q.queue, q.spill,
-                               n_batches, q.chunk_batches, n_chunks, nullptr);
+                               n_batches, q.chunk_batches, n_chunks, q.cut, nullptr);
         return hipGetLastError();
     }
 } // namespace icp_dev

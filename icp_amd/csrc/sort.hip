@@ -1,5 +1,12 @@
 // Spatial ordering of the cloud to move (set-up path, once per icp_hip_set_queries).
 //
+// Two stable sorts: Morton order of the positions, then (when the tree is already on the device)
+// the index of the leaf a near-only descent of the centred point ends in.  Leaves are numbered
+// left to right, so the final order is "by leaf region, Morton inside a region": at the first
+// iteration the 64 queries of a wave wait on one or two buckets, and after the cloud has moved
+// the order is still a tighter clustering than the plain Z-curve.  The keys only shape the
+// order of evaluation; they need not be (and are not) bit-faithful to the search's decisions.
+//
 // The reference processes queries in input order (vp-tree.cc:182-184); every query is independent,
 // so the order is free.  Here the shard is stored in Morton (Z-curve) order of the points'
 // positions: the 64 queries of a wave are then neighbours in space, walk the same tree path and
@@ -85,6 +92,44 @@ namespace icp_dev
             }
         }
 
+        // key = index of the leaf reached by always taking the near child (d < radius)
+        __global__ void __launch_bounds__(kBlock)
+            leaf_key_kernel(DevTree t, const float* __restrict__ px, const float* __restrict__ py,
+                            const float* __restrict__ pz, float mux, float muy, float muz, uint32_t n,
+                            uint32_t* __restrict__ keys, uint32_t* __restrict__ idx)
+        {
+            for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+            {
+                const float qx = px[i] - mux, qy = py[i] - muy, qz = pz[i] - muz;
+                int node = t.root;
+                while (node >= 0)
+                {
+                    const DevNode N = t.nodes[node];
+                    const float dx = qx - N.cx, dy = qy - N.cy, dz = qz - N.cz;
+                    node = (dx * dx + dy * dy + dz * dz < N.r * N.r) ? N.inside : N.outside;
+                }
+                keys[i] = (uint32_t)~node;
+                idx[i] = i;
+            }
+        }
+
+        __global__ void __launch_bounds__(kBlock)
+            permute_soa_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                               const float* __restrict__ z, const uint32_t* __restrict__ perm,
+                               const uint32_t* __restrict__ order, uint32_t n, float* __restrict__ ox,
+                               float* __restrict__ oy, float* __restrict__ oz,
+                               uint32_t* __restrict__ operm)
+        {
+            for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+            {
+                const uint32_t r = order[i];
+                ox[i] = x[r];
+                oy[i] = y[r];
+                oz[i] = z[r];
+                operm[i] = perm[r];
+            }
+        }
+
         __global__ void __launch_bounds__(kBlock)
             gather_soa_kernel(const float* __restrict__ aos, const uint32_t* __restrict__ perm,
                               uint32_t n, float* __restrict__ x, float* __restrict__ y,
@@ -129,21 +174,39 @@ namespace icp_dev
         return hipGetLastError();
     }
 
-    // Stable LSD radix sort of (key, idx) pairs on 30-bit keys.  Set-up path: allocates and frees
+    hipError_t launch_leaf_keys(const DevTree& t, const float* px, const float* py, const float* pz,
+                                const float mu[3], uint32_t n, uint32_t* keys, uint32_t* idx,
+                                hipStream_t s)
+    {
+        hipLaunchKernelGGL(leaf_key_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, s, t, px, py, pz,
+                           mu[0], mu[1], mu[2], n, keys, idx);
+        return hipGetLastError();
+    }
+
+    hipError_t launch_permute_soa(const float* x, const float* y, const float* z,
+                                  const uint32_t* perm, const uint32_t* order, uint32_t n, float* ox,
+                                  float* oy, float* oz, uint32_t* operm, hipStream_t s)
+    {
+        hipLaunchKernelGGL(permute_soa_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, s, x, y, z,
+                           perm, order, n, ox, oy, oz, operm);
+        return hipGetLastError();
+    }
+
+    // Stable LSD radix sort of (key, idx) pairs on the low `bits` bits of the keys.  Set-up path: allocates and frees
     // rocPRIM's temporary storage.
     hipError_t sort_pairs_u32(const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* idx_in,
-                              uint32_t* idx_out, uint32_t n, hipStream_t s)
+                              uint32_t* idx_out, uint32_t n, uint32_t bits, hipStream_t s)
     {
         size_t bytes = 0;
         hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, keys_in, keys_out, idx_in, idx_out,
-                                                 (size_t)n, 0u, 30u, s);
+                                                 (size_t)n, 0u, bits, s);
         if (e != hipSuccess)
             return e;
         void* tmp = nullptr;
         if ((e = hipMalloc(&tmp, bytes ? bytes : 16)) != hipSuccess)
             return e;
         e = rocprim::radix_sort_pairs(tmp, bytes, keys_in, keys_out, idx_in, idx_out, (size_t)n, 0u,
-                                      30u, s);
+                                      bits, s);
         hipError_t e2 = hipStreamSynchronize(s);
         (void)hipFree(tmp);
         return e != hipSuccess ? e : e2;
