@@ -50,7 +50,8 @@ class FlatTreeStruct(C.Structure):
 class TimingStruct(C.Structure):
     _fields_ = [("nn_launches", C.c_uint64), ("nn_ms", C.c_double), ("apply_ms", C.c_double),
                 ("reduce_ms", C.c_double), ("host_ms", C.c_double), ("queries", C.c_double),
-                ("nodes_visited", C.c_double), ("points_scanned", C.c_double)]
+                ("nodes_visited", C.c_double), ("points_scanned", C.c_double),
+                ("stack_spills", C.c_double)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int, C.c_void_p)

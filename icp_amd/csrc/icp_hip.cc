@@ -780,6 +780,7 @@ extern "C"
         c->timing.nn_ms += ms;
         c->timing.nodes_visited += c->h_sums[9];   // this shard only (no all-reduce here)
         c->timing.points_scanned += c->h_sums[10];
+        c->timing.stack_spills += c->h_sums[11];
         c->timing.queries += (double)n;
         if (kernel_ms)
             *kernel_ms = ms;
@@ -895,6 +896,7 @@ extern "C"
                 c->timing.nn_launches += 1;
                 c->timing.nodes_visited += c->h_sums[9];
                 c->timing.points_scanned += c->h_sums[10];
+                c->timing.stack_spills += c->h_sums[11];
                 c->timing.queries += (double)c->n_total;
                 if (c->nn_trace.size() < 4096)
                     c->nn_trace.push_back(ms);

@@ -268,6 +268,8 @@ namespace icp_dev
             win_out = win;
         }
 
+    } // namespace
+
         template <bool STATS>
         __global__ void __launch_bounds__(kBlock, 5) // 5 workgroups per CU (LDS: 5 x 32 KiB)
             nn_tile_kernel(DevTree t, const float* __restrict__ px, const float* __restrict__ py,
@@ -638,8 +640,6 @@ namespace icp_dev
                 (void)st_tile_len;
             }
         }
-    } // namespace
-
     hipError_t nn_tile_blocks_per_cu(int* out)
     {
         return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, nn_tile_kernel<false>, kBlock, 0);
