@@ -161,11 +161,32 @@ def main():
                 traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    # Reading the fraction: the algorithmic bytes charge every query for the bucket points and
+    # nodes ITS traversal reads.  The shard is stored in leaf order, so the queries of
+    # a wave share buckets, which the tile scan stages once in LDS: achieved can exceed the HBM
+    # peak; `traffic` (HBM bytes per launch from the FETCH_SIZE/WRITE_SIZE passes under
+    # profiles/) is what actually crosses the memory interface.  The kernel is then bound by
+    # VALU issue: `valu` prices the traversal's fp32 operations (8 per distance: 3 sub, 3 mul,
+    # 2 add, never contracted to FMA because the answers must be the reference's bit for bit)
+    # against the non-FMA vector rate, 256 CUs x 128 lanes x 2.4 GHz.
+    n_gpu = float(end - begin)
+    tree_bytes = 12.0 * tree.n_slots + 32.0 * tree.n_nodes
+    compulsory = 16.0 * n_gpu + min(tree_bytes, bytes_per_launch)
+    flops_per_launch = 8.0 * (tm["points_scanned"] + tm["nodes_visited"]) / launches / world
+    valu_peak = 256 * 128 * 2.4e9 / 1e12
+    valu_ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": "nn_cov_kernel", "avg_launch_ms": round(avg_ms, 4),
+                "kernel": "nn_tile_kernel", "avg_launch_ms": round(avg_ms, 4),
                 "launches": launches, "algorithmic_bytes_per_launch": round(bytes_per_launch),
-                "bytes_per_query": round(alg_bytes_all / max(1.0, tm["queries"]), 1)}
+                "bytes_per_query": round(alg_bytes_all / max(1.0, tm["queries"]), 1),
+                "compulsory_bytes_per_launch": round(compulsory),
+                "hbm_traffic_frac": (round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                     if traffic else None),
+                "valu": {"achieved": round(valu_ach, 2), "peak": round(valu_peak, 2),
+                         "unit": "Tflop/s (fp32, no FMA)", "frac": round(valu_ach / valu_peak, 4),
+                         "flops_per_launch": round(flops_per_launch)},
+                "stack_spills": tm.get("stack_spills", 0.0)}
 
     out = None
     if rank == 0:
