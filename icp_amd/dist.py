@@ -1,7 +1,7 @@
 """One process per GPU: shard bounds and the per-iteration all-reduce of the small sums.
 
 The path shards over the points to move (each is an independent NN query); the only exchange is
-one all-reduce of 11 doubles after the NN pass and one of 4 doubles after the apply pass, per
+one all-reduce of 12 doubles after the NN pass and one of 4 doubles after the apply pass, per
 iteration (include/icp_hip.h: icp_hip_set_allreduce / icp_hip_comm_init_rank).  The reference has
 no counterpart (it is single-device); the parity target is the single-GPU result.
 """

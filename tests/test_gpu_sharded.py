@@ -24,3 +24,28 @@ def test_two_contexts_match_one(tmp_path):
     assert res[0]["T"] == res[1]["T"]
     new_p = np.concatenate([np.array(r["new_p"], np.float32) for r in res])
     assert new_p.shape == new_p1.shape and np.abs(new_p - new_p1).max() <= 1e-6
+
+
+def test_rccl_communicator_single_rank():
+    """The RCCL leg (icp_hip_comm_init_rank: dlopen of librccl, ncclAllReduce of the sums on the
+    context's stream) with a communicator of one rank: same bits as the run without it.  More
+    ranks need more GPUs than the test box has; bench.py --gpus N takes this same path."""
+    from icp_amd import capi, synth
+    n, cap = 50_000, 64
+    m = synth.cloud(n, seed=31)
+    p = synth.apply_fp32(m, synth.ground_truth(2.0))
+    mu_m = capi.mean_host(m)
+    tree = capi.FlatTree(capi.center_host(m, mu_m), cap)
+    out = []
+    for use_comm in (False, True):
+        with capi.Context() as ctx:
+            ctx.set_tree(tree)
+            if use_comm:
+                ctx.comm_init_rank(1, 0, capi.Context.comm_unique_id())
+            ctx.set_queries(p)
+            T, iters, err = ctx.run(mu_m, 30, 1e-5)
+            out.append((T.copy(), iters, err, ctx.get_points()))
+    tree.close()
+    assert out[0][1] == out[1][1] and out[0][2] == out[1][2]
+    assert (out[0][0].view(np.uint32) == out[1][0].view(np.uint32)).all()
+    assert (out[0][3].view(np.uint32) == out[1][3].view(np.uint32)).all()
