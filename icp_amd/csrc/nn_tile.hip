@@ -41,10 +41,11 @@ namespace icp_dev
 {
     namespace
     {
-        constexpr int kStackK = 7;  // LDS stack entries per lane
+        constexpr int kStackK = 4;  // LDS stack entries per lane
         constexpr int kImage = 256; // bucket slots staged per window
         constexpr int kGroups = kImage / 4; // float4 groups of the image; group kGroups is +inf
         constexpr int kTileMinGroup = 3; // fewer lanes on a bucket: whole-wave scan per lane
+        constexpr int kTileSplitBelow = 56; // 33..55 lanes: scan as 32 + rest (see the leaf phase)
 
         enum : int
         {
@@ -138,7 +139,7 @@ namespace icp_dev
                 uint32_t gi = idle ? (uint32_t)kGroups : part; // group of this lane at step 0
                 const float m_before = m;
                 uint32_t kbest = 0;
-#pragma nounroll
+#pragma unroll 2
                 for (uint32_t k = 0; k < steps; ++k)
                 {
                     const uint32_t gc = min(gi, (uint32_t)kGroups); // group 64 is all +inf
@@ -271,7 +272,7 @@ namespace icp_dev
     } // namespace
 
         template <bool STATS>
-        __global__ void __launch_bounds__(kBlock, 5) // 5 workgroups per CU (LDS: 5 x 32 KiB)
+        __global__ void __launch_bounds__(kBlock, 6) // 6 workgroups per CU (LDS 6 x 24.7 KiB, <= 80 VGPRs)
             nn_tile_kernel(DevTree t, const float* __restrict__ px, const float* __restrict__ py,
                            const float* __restrict__ pz, float mux, float muy, float muz, uint32_t n,
                            float* __restrict__ yx, float* __restrict__ yy, float* __restrict__ yz,
@@ -494,23 +495,37 @@ namespace icp_dev
                         const bool member = (mode == tWaitLeaf) && (lbeg == beg);
                         const uint64_t grp = __ballot(member);
                         pend &= ~grp;
-                        if (__builtin_popcountll(grp) >= kTileMinGroup)
+                        const int g_all = __builtin_popcountll(grp);
+                        if (g_all >= kTileMinGroup)
                         {
-                            float m, m2;
-                            uint32_t idx;
-                            tile_scan(t, L, beg, cnt, grp, member, qx, qy, qz, lane, m, m2, idx);
-                            if (STATS)
+                            // 33..55 lanes would leave the tile half empty (one part only):
+                            // serve the first 32 as two parts, then the rest as their own group
+                            const bool split = g_all > 32 && g_all < kTileSplitBelow;
+                            const uint32_t rank_all = __builtin_amdgcn_mbcnt_hi(
+                                (uint32_t)(grp >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)grp, 0u));
+                            uint64_t rest = grp;
+                            while (rest)
                             {
-                                st_tile += 1u;
-                                st_tile_g += (uint32_t)__builtin_popcountll(grp);
-                            }
-                            if (member)
-                            {
-                                const bool unique =
-                                    (__float_as_uint(m2) - __float_as_uint(m)) > 4u;
-                                rd = m;
-                                rid = beg + idx;
-                                mode = unique ? tServed : tWaitExact;
+                                const bool mem =
+                                    member && (rest == grp ? (!split || rank_all < 32u) : rank_all >= 32u);
+                                const uint64_t sub = __ballot(mem);
+                                rest &= ~sub;
+                                float m, m2;
+                                uint32_t idx;
+                                tile_scan(t, L, beg, cnt, sub, mem, qx, qy, qz, lane, m, m2, idx);
+                                if (STATS)
+                                {
+                                    st_tile += 1u;
+                                    st_tile_g += (uint32_t)__builtin_popcountll(sub);
+                                }
+                                if (mem)
+                                {
+                                    const bool unique =
+                                        (__float_as_uint(m2) - __float_as_uint(m)) > 4u;
+                                    rd = m;
+                                    rid = beg + idx;
+                                    mode = unique ? tServed : tWaitExact;
+                                }
                             }
                         }
                         else if (cnt <= (uint32_t)kImage)
