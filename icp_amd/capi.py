@@ -20,7 +20,8 @@ STATUS = {0: "OK", 1: "ERR_ARG", 2: "ERR_DEGENERATE", 3: "ERR_HIP", 4: "ERR_COMM
 EXPORTS = [
     "icp_hip_tree_build", "icp_hip_tree_free", "icp_hip_tree_validate", "icp_hip_mean_host",
     "icp_hip_center_host", "icp_hip_alignment_host", "icp_hip_create", "icp_hip_destroy", "icp_hip_last_error",
-    "icp_hip_last_global_error", "icp_hip_set_tree", "icp_hip_set_queries", "icp_hip_nn",
+    "icp_hip_last_global_error", "icp_hip_set_tree", "icp_hip_build_tree", "icp_hip_get_tree",
+    "icp_hip_set_queries", "icp_hip_nn",
     "icp_hip_set_allreduce", "icp_hip_comm_unique_id", "icp_hip_comm_init_rank", "icp_hip_run",
     "icp_hip_get_points", "icp_hip_get_timing", "icp_hip_get_nn_trace",
 ]
@@ -89,6 +90,8 @@ def load() -> C.CDLL:
     L.icp_hip_last_error.restype = C.c_char_p
     L.icp_hip_last_global_error.restype = C.c_char_p
     L.icp_hip_set_tree.argtypes = [vp, treep]
+    L.icp_hip_build_tree.argtypes = [vp, vp, u64, u32]
+    L.icp_hip_get_tree.argtypes = [vp, C.POINTER(treep)]
     L.icp_hip_set_queries.argtypes = [vp, vp, u64, u64]
     L.icp_hip_nn.argtypes = [vp, vp, vp, vp, vp, C.POINTER(C.c_float)]
     L.icp_hip_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp]
@@ -146,8 +149,11 @@ def alignment_host(H, mu_p, mu_m) -> np.ndarray:
 class FlatTree:
     """Owns an icp_flat_tree built by icp_hip_tree_build; numpy views into its arrays."""
 
-    def __init__(self, xyz_centered, capacity: int):
+    def __init__(self, xyz_centered, capacity: int, _adopt=None):
         L = load()
+        if _adopt is not None:  # a tree the library handed out (icp_hip_get_tree)
+            self._ptr = _adopt
+            return
         a = _pts(xyz_centered)
         self._ptr = C.POINTER(FlatTreeStruct)()
         _check(L.icp_hip_tree_build(a.ctypes.data, len(a), int(capacity), C.byref(self._ptr)))
@@ -214,6 +220,16 @@ class Context:
 
     def set_tree(self, tree: FlatTree):
         _check(self._L.icp_hip_set_tree(self._h, tree._ptr), self._h)
+
+    def build_tree(self, xyz_centered, capacity: int):
+        """Build the reference's VP-tree on the device (icp_hip_build_tree)."""
+        a = _pts(xyz_centered)
+        _check(self._L.icp_hip_build_tree(self._h, a.ctypes.data, len(a), int(capacity)), self._h)
+
+    def get_tree(self) -> "FlatTree":
+        ptr = C.POINTER(FlatTreeStruct)()
+        _check(self._L.icp_hip_get_tree(self._h, C.byref(ptr)), self._h)
+        return FlatTree(None, 0, _adopt=ptr)
 
     def set_tree_struct(self, struct: FlatTreeStruct):
         _check(self._L.icp_hip_set_tree(self._h, C.byref(struct)), self._h)

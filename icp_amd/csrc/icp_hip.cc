@@ -18,6 +18,7 @@
 #include "host_common.hh"
 #include "icp_hip.h"
 #include "kernels.hh"
+#include "tree_build.hh"
 
 using namespace icp_dev;
 
@@ -115,7 +116,7 @@ struct icp_hip_ctx
     // tree replica
     bool has_tree = false;
     DevTree tree{};
-    uint32_t height = 0, max_leaf = 0;
+    uint32_t height = 0, max_leaf = 0, capacity = 0;
     uint64_t n_tree_points = 0;
     DevBuf<DevNode> nodes;
     DevBuf<uint2> leaf_info;
@@ -433,6 +434,103 @@ namespace
         }
         return ICP_HIP_OK;
     }
+
+    // Put a tree on the device: node records + leaf table from host arrays; the bucket slots are
+    // either uploaded from the host arrays of `t` or, when d_sx is not null, adopted from device
+    // arrays that tree_build.hip filled (n_slots + kSlotSlack floats, +inf behind n_slots).
+    int install_tree(icp_hip_ctx* c, const icp_flat_tree* t, float* d_sx, float* d_sy, float* d_sz,
+                     uint32_t* d_srow)
+    {
+        if ((int)t->height > nn_max_depth_supported())
+            return fail(c, ICP_HIP_ERR_DEPTH,
+                        "icp_hip_set_tree: tree height " + std::to_string(t->height) +
+                            " exceeds the traversal stack (" +
+                            std::to_string(nn_max_depth_supported()) + " levels)");
+        c->has_tree = false;
+        const size_t nn = t->n_nodes, nl = t->n_leaves, ns = t->n_slots;
+        const size_t slack = kSlotSlack; // bucket windows / chunks are loaded whole
+
+        // staging for the SoA node arrays, packed into 32-byte records on the device
+        DevBuf<float> f4[4];
+        DevBuf<int32_t> i3[3];
+        auto cleanup = [&]() {
+            for (auto& b : f4)
+                b.release();
+            for (auto& b : i3)
+                b.release();
+        };
+        hipError_t e = hipSuccess;
+        auto up = [&](auto& buf, const auto* src, size_t n) -> bool {
+            if ((e = buf.alloc(n)) != hipSuccess)
+                return false;
+            if (n == 0)
+                return true;
+            e = hipMemcpyAsync(buf.p, src, n * sizeof(*src), hipMemcpyHostToDevice, c->stream);
+            return e == hipSuccess;
+        };
+        bool ok = c->nodes.alloc(nn ? nn : 1) == hipSuccess;
+        ok = ok && up(f4[0], t->node_cx, nn) && up(f4[1], t->node_cy, nn) &&
+             up(f4[2], t->node_cz, nn) && up(f4[3], t->node_radius, nn) &&
+             up(i3[0], t->node_inside, nn) && up(i3[1], t->node_outside, nn) &&
+             up(i3[2], t->node_parent, nn) && up(c->nrow, t->node_row, nn);
+        if (ok && nn)
+            ok = (e = launch_pack_nodes(f4[0].p, f4[1].p, f4[2].p, f4[3].p, i3[0].p, i3[1].p,
+                                        i3[2].p, (uint32_t)nn, c->nodes.p, c->stream)) ==
+                 hipSuccess;
+        // leaves {begin,count}
+        std::vector<uint2> li(nl);
+        for (size_t l = 0; l < nl; ++l)
+            li[l] = make_uint2(t->leaf_begin[l], t->leaf_count[l]);
+        ok = ok && up(c->leaf_info, li.data(), nl);
+        // bucket slots (+slack filled with +inf so stray lanes compute inf, never NaN)
+        auto up_slots = [&](DevBuf<float>& buf, const float* src) -> bool {
+            if ((e = buf.alloc(ns + slack)) != hipSuccess)
+                return false;
+            if ((e = hipMemcpyAsync(buf.p, src, ns * sizeof(float), hipMemcpyHostToDevice,
+                                    c->stream)) != hipSuccess)
+                return false;
+            static const std::vector<float> inf(slack, std::numeric_limits<float>::infinity());
+            e = hipMemcpyAsync(buf.p + ns, inf.data(), slack * sizeof(float),
+                               hipMemcpyHostToDevice, c->stream);
+            return e == hipSuccess;
+        };
+        if (d_sx)
+        {
+            c->sx.release();
+            c->sy.release();
+            c->sz.release();
+            c->srow.release();
+            c->sx.p = d_sx, c->sx.count = ns + slack;
+            c->sy.p = d_sy, c->sy.count = ns + slack;
+            c->sz.p = d_sz, c->sz.count = ns + slack;
+            c->srow.p = d_srow, c->srow.count = ns;
+        }
+        else
+            ok = ok && up_slots(c->sx, t->slot_x) && up_slots(c->sy, t->slot_y) &&
+                 up_slots(c->sz, t->slot_z) && up(c->srow, t->slot_row, ns);
+        if (ok)
+            ok = (e = hipStreamSynchronize(c->stream)) == hipSuccess;
+        cleanup();
+        if (!ok)
+            return hip_fail(c, e, "icp_hip_set_tree upload");
+
+        c->tree.nodes = c->nodes.p;
+        c->tree.leaf_info = c->leaf_info.p;
+        c->tree.sx = c->sx.p;
+        c->tree.sy = c->sy.p;
+        c->tree.sz = c->sz.p;
+        c->tree.srow = c->srow.p;
+        c->tree.nrow = c->nrow.p;
+        c->tree.n_slots = (uint32_t)ns;
+        c->tree.n_nodes = (uint32_t)nn;
+        c->tree.root = t->root;
+        c->height = t->height;
+        c->max_leaf = t->max_leaf_count;
+        c->capacity = t->capacity;
+        c->n_tree_points = t->n_points;
+        c->has_tree = true;
+        return prepare_tile(c);
+    }
 } // namespace
 
 extern "C"
@@ -619,83 +717,164 @@ extern "C"
             if (rc != ICP_HIP_OK)
                 return fail(c, rc, err);
         }
-        if ((int)t->height > nn_max_depth_supported())
-            return fail(c, ICP_HIP_ERR_DEPTH,
-                        "icp_hip_set_tree: tree height " + std::to_string(t->height) +
-                            " exceeds the traversal stack (" +
-                            std::to_string(nn_max_depth_supported()) + " levels)");
+        DeviceGuard g(c->device);
+        return install_tree(c, t, nullptr, nullptr, nullptr, nullptr);
+    }
+
+    int icp_hip_build_tree(icp_hip_ctx* c, const float* xyz_centered, uint64_t n, uint32_t capacity)
+    {
+        if (!c)
+            return fail(nullptr, ICP_HIP_ERR_ARG, "icp_hip_build_tree: ctx is NULL");
+        if (!xyz_centered || n == 0)
+            return fail(c, ICP_HIP_ERR_ARG, "icp_hip_build_tree: empty cloud");
+        if (n >= (1ull << 31))
+            return fail(c, ICP_HIP_ERR_ARG,
+                        "icp_hip_build_tree: more than 2^31-1 points are not supported");
+        if (capacity < 3)
+            return fail(c, ICP_HIP_ERR_DEGENERATE,
+                        "icp_hip_build_tree: capacity <= 2 is undefined behaviour in the reference "
+                        "(vp-tree.cc:114: empty inside set on 2-point nodes)");
         DeviceGuard g(c->device);
         c->has_tree = false;
-        const size_t nn = t->n_nodes, nl = t->n_leaves, ns = t->n_slots;
-        const size_t slack = kSlotSlack; // bucket windows / chunks are loaded whole
+        DevBuf<float> cloud;
+        HIP_TRY(c, cloud.alloc(3 * n));
+        struct Free
+        {
+            DevBuf<float>& b;
+            ~Free() { b.release(); }
+        } free_cloud{cloud};
+        HIP_TRY(c, hipMemcpyAsync(cloud.p, xyz_centered, 3 * n * sizeof(float),
+                                  hipMemcpyHostToDevice, c->stream));
+        BuiltTree bt;
+        std::string err;
+        int rc;
+        try
+        {
+            rc = build_tree_device(cloud.p, (uint32_t)n, capacity, c->stream, bt, err);
+        }
+        catch (const std::bad_alloc&)
+        {
+            rc = ICP_HIP_ERR_NOMEM;
+            err = "icp_hip_build_tree: out of host memory";
+        }
+        if (rc != ICP_HIP_OK)
+            return fail(c, rc, "icp_hip_build_tree: " + err);
+        icp_flat_tree v{};
+        v.n_points = bt.n_points;
+        v.n_slots = bt.n_slots;
+        v.n_nodes = (uint32_t)bt.node_cx.size();
+        v.n_leaves = (uint32_t)bt.leaf_begin.size();
+        v.height = bt.height;
+        v.capacity = bt.capacity;
+        v.max_leaf_count = bt.max_leaf_count;
+        v.root = bt.root;
+        v.node_cx = bt.node_cx.data();
+        v.node_cy = bt.node_cy.data();
+        v.node_cz = bt.node_cz.data();
+        v.node_radius = bt.node_radius.data();
+        v.node_inside = bt.node_inside.data();
+        v.node_outside = bt.node_outside.data();
+        v.node_parent = bt.node_parent.data();
+        v.node_row = bt.node_row.data();
+        v.leaf_begin = bt.leaf_begin.data();
+        v.leaf_count = bt.leaf_count.data();
+        if ((int)v.height > nn_max_depth_supported())
+        {
+            (void)hipFree(bt.d_sx);
+            (void)hipFree(bt.d_sy);
+            (void)hipFree(bt.d_sz);
+            (void)hipFree(bt.d_srow);
+            return fail(c, ICP_HIP_ERR_DEPTH, "icp_hip_build_tree: tree too deep");
+        }
+        return install_tree(c, &v, bt.d_sx, bt.d_sy, bt.d_sz, bt.d_srow);
+    }
 
-        // staging for the SoA node arrays, packed into 32-byte records on the device
-        DevBuf<float> f4[4];
-        DevBuf<int32_t> i3[3];
-        auto cleanup = [&]() {
-            for (auto& b : f4)
-                b.release();
-            for (auto& b : i3)
-                b.release();
-        };
-        hipError_t e = hipSuccess;
-        auto up = [&](auto& buf, const auto* src, size_t n) -> bool {
-            if ((e = buf.alloc(n)) != hipSuccess)
-                return false;
-            if (n == 0)
-                return true;
-            e = hipMemcpyAsync(buf.p, src, n * sizeof(*src), hipMemcpyHostToDevice, c->stream);
-            return e == hipSuccess;
-        };
-        bool ok = c->nodes.alloc(nn ? nn : 1) == hipSuccess;
-        ok = ok && up(f4[0], t->node_cx, nn) && up(f4[1], t->node_cy, nn) &&
-             up(f4[2], t->node_cz, nn) && up(f4[3], t->node_radius, nn) &&
-             up(i3[0], t->node_inside, nn) && up(i3[1], t->node_outside, nn) &&
-             up(i3[2], t->node_parent, nn) && up(c->nrow, t->node_row, nn);
-        if (ok && nn)
-            ok = (e = launch_pack_nodes(f4[0].p, f4[1].p, f4[2].p, f4[3].p, i3[0].p, i3[1].p,
-                                        i3[2].p, (uint32_t)nn, c->nodes.p, c->stream)) ==
-                 hipSuccess;
-        // leaves {begin,count}
-        std::vector<uint2> li(nl);
-        for (size_t l = 0; l < nl; ++l)
-            li[l] = make_uint2(t->leaf_begin[l], t->leaf_count[l]);
-        ok = ok && up(c->leaf_info, li.data(), nl);
-        // bucket slots (+slack filled with +inf so stray lanes compute inf, never NaN)
-        auto up_slots = [&](DevBuf<float>& buf, const float* src) -> bool {
-            if ((e = buf.alloc(ns + slack)) != hipSuccess)
-                return false;
-            if ((e = hipMemcpyAsync(buf.p, src, ns * sizeof(float), hipMemcpyHostToDevice,
-                                    c->stream)) != hipSuccess)
-                return false;
-            static const std::vector<float> inf(slack, std::numeric_limits<float>::infinity());
-            e = hipMemcpyAsync(buf.p + ns, inf.data(), slack * sizeof(float),
-                               hipMemcpyHostToDevice, c->stream);
-            return e == hipSuccess;
-        };
-        ok = ok && up_slots(c->sx, t->slot_x) && up_slots(c->sy, t->slot_y) &&
-             up_slots(c->sz, t->slot_z) && up(c->srow, t->slot_row, ns);
-        if (ok)
-            ok = (e = hipStreamSynchronize(c->stream)) == hipSuccess;
-        cleanup();
-        if (!ok)
-            return hip_fail(c, e, "icp_hip_set_tree upload");
-
-        c->tree.nodes = c->nodes.p;
-        c->tree.leaf_info = c->leaf_info.p;
-        c->tree.sx = c->sx.p;
-        c->tree.sy = c->sy.p;
-        c->tree.sz = c->sz.p;
-        c->tree.srow = c->srow.p;
-        c->tree.nrow = c->nrow.p;
-        c->tree.n_slots = (uint32_t)ns;
-        c->tree.n_nodes = (uint32_t)nn;
-        c->tree.root = t->root;
-        c->height = t->height;
-        c->max_leaf = t->max_leaf_count;
-        c->n_tree_points = t->n_points;
-        c->has_tree = true;
-        return prepare_tile(c);
+    int icp_hip_get_tree(icp_hip_ctx* c, icp_flat_tree** out)
+    {
+        if (!c || !out)
+            return fail(c, ICP_HIP_ERR_ARG, "icp_hip_get_tree: NULL argument");
+        *out = nullptr;
+        if (!c->has_tree)
+            return fail(c, ICP_HIP_ERR_ARG, "icp_hip_get_tree: no tree on the device");
+        DeviceGuard g(c->device);
+        icp_host::FlatTreeOwner* T = nullptr;
+        try
+        {
+            T = new icp_host::FlatTreeOwner();
+            const size_t nn = c->tree.n_nodes, nl = c->leaf_info.count, ns = c->tree.n_slots;
+            std::vector<DevNode> nodes(nn);
+            std::vector<uint2> li(nl);
+            T->node_row.resize(nn);
+            T->slot_x.resize(ns);
+            T->slot_y.resize(ns);
+            T->slot_z.resize(ns);
+            T->slot_row.resize(ns);
+            auto down = [&](void* dst, const void* src, size_t bytes) {
+                return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream)
+                             : hipSuccess;
+            };
+            hipError_t e = down(nodes.data(), c->nodes.p, nn * sizeof(DevNode));
+            if (e == hipSuccess)
+                e = down(T->node_row.data(), c->nrow.p, nn * sizeof(uint32_t));
+            if (e == hipSuccess)
+                e = down(li.data(), c->leaf_info.p, nl * sizeof(uint2));
+            if (e == hipSuccess)
+                e = down(T->slot_x.data(), c->sx.p, ns * sizeof(float));
+            if (e == hipSuccess)
+                e = down(T->slot_y.data(), c->sy.p, ns * sizeof(float));
+            if (e == hipSuccess)
+                e = down(T->slot_z.data(), c->sz.p, ns * sizeof(float));
+            if (e == hipSuccess)
+                e = down(T->slot_row.data(), c->srow.p, ns * sizeof(uint32_t));
+            if (e == hipSuccess)
+                e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess)
+            {
+                delete T;
+                return hip_fail(c, e, "icp_hip_get_tree download");
+            }
+            T->node_cx.resize(nn);
+            T->node_cy.resize(nn);
+            T->node_cz.resize(nn);
+            T->node_radius.resize(nn);
+            T->node_inside.resize(nn);
+            T->node_outside.resize(nn);
+            T->node_parent.resize(nn);
+            for (size_t i = 0; i < nn; ++i)
+            {
+                T->node_cx[i] = nodes[i].cx;
+                T->node_cy[i] = nodes[i].cy;
+                T->node_cz[i] = nodes[i].cz;
+                T->node_radius[i] = nodes[i].r;
+                T->node_inside[i] = nodes[i].inside;
+                T->node_outside[i] = nodes[i].outside;
+                T->node_parent[i] = nodes[i].parent;
+            }
+            T->leaf_begin.resize(nl);
+            T->leaf_count.resize(nl);
+            for (size_t l = 0; l < nl; ++l)
+            {
+                T->leaf_begin[l] = li[l].x;
+                T->leaf_count[l] = li[l].y;
+            }
+            icp_flat_tree& v = T->view;
+            v.n_points = c->n_tree_points;
+            v.n_slots = ns;
+            v.n_nodes = (uint32_t)nn;
+            v.n_leaves = (uint32_t)nl;
+            v.height = c->height;
+            v.capacity = c->capacity;
+            v.max_leaf_count = c->max_leaf;
+            v.root = c->tree.root;
+            T->sync_view();
+        }
+        catch (const std::bad_alloc&)
+        {
+            delete T;
+            return fail(c, ICP_HIP_ERR_NOMEM, "icp_hip_get_tree: out of host memory");
+        }
+        *out = &T->view;
+        return ICP_HIP_OK;
     }
 
     int icp_hip_set_queries(icp_hip_ctx* c, const float* xyz_aos, uint64_t n_local,

@@ -128,6 +128,19 @@ const char* icp_hip_last_global_error(void);
  * for the duration of the call. */
 int icp_hip_set_tree(icp_hip_ctx* ctx, const icp_flat_tree* tree);
 
+/* Device-side tree build: replaces libcpu::VPTree::VPTree (libcpu/libcpu/vp-tree.cc:54-123, with
+ * partition/select/median :7-52) as called from libgpu::icp (libgpu/libgpu/icp.cu:141-142) AND
+ * GPUVPTree::from_cpu (vp-tree.cu:58-112) in one step: `xyz_centered` (host, Point3D layout, the
+ * reference cloud centred on its mean) is uploaded once and the tree is built level by level in
+ * HBM, straight into the layout the kernels read.  The tree is the one icp_hip_tree_build makes
+ * (hence the reference's), bit for bit; icp_hip_get_tree returns it for inspection.  Same error
+ * conventions as icp_hip_tree_build (ICP_HIP_ERR_DEGENERATE where the reference is undefined). */
+int icp_hip_build_tree(icp_hip_ctx* ctx, const float* xyz_centered, uint64_t n, uint32_t capacity);
+/* Host copy of the context's tree in the flat layout (whichever way it got there).  No reference
+ * counterpart beyond the friend access of GPUVPTree (libcpu/libcpu/vp-tree.hh:8-17); used by the
+ * tests and to cache a tree.  Free with icp_hip_tree_free. */
+int icp_hip_get_tree(icp_hip_ctx* ctx, icp_flat_tree** out);
+
 /* Upload this context's contiguous shard of the cloud to move ("p", icp.hh:20).
  * Replaces GPUMatrix::from_point_list (libgpu/libgpu/matrix.cu:95-103).
  * n_total is the size of the whole cloud over all shards (== n_local on one GPU). */
