@@ -21,6 +21,7 @@ EXPORTS = [
     "icp_hip_tree_build", "icp_hip_tree_free", "icp_hip_tree_validate", "icp_hip_mean_host",
     "icp_hip_center_host", "icp_hip_alignment_host", "icp_hip_create", "icp_hip_destroy", "icp_hip_last_error",
     "icp_hip_last_global_error", "icp_hip_set_tree", "icp_hip_build_tree", "icp_hip_get_tree",
+    "icp_hip_get_tree_info",
     "icp_hip_set_queries", "icp_hip_nn",
     "icp_hip_set_allreduce", "icp_hip_comm_unique_id", "icp_hip_comm_init_rank", "icp_hip_run",
     "icp_hip_get_points", "icp_hip_get_timing", "icp_hip_get_nn_trace",
@@ -92,6 +93,7 @@ def load() -> C.CDLL:
     L.icp_hip_set_tree.argtypes = [vp, treep]
     L.icp_hip_build_tree.argtypes = [vp, vp, u64, u32]
     L.icp_hip_get_tree.argtypes = [vp, C.POINTER(treep)]
+    L.icp_hip_get_tree_info.argtypes = [vp, treep]
     L.icp_hip_set_queries.argtypes = [vp, vp, u64, u64]
     L.icp_hip_nn.argtypes = [vp, vp, vp, vp, vp, C.POINTER(C.c_float)]
     L.icp_hip_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp]
@@ -225,6 +227,12 @@ class Context:
         """Build the reference's VP-tree on the device (icp_hip_build_tree)."""
         a = _pts(xyz_centered)
         _check(self._L.icp_hip_build_tree(self._h, a.ctypes.data, len(a), int(capacity)), self._h)
+
+    def tree_info(self) -> dict:
+        t = FlatTreeStruct()
+        _check(self._L.icp_hip_get_tree_info(self._h, C.byref(t)), self._h)
+        return {k: getattr(t, k) for k in ("n_points", "n_slots", "n_nodes", "n_leaves", "height",
+                                           "capacity", "max_leaf_count", "root")}
 
     def get_tree(self) -> "FlatTree":
         ptr = C.POINTER(FlatTreeStruct)()

@@ -789,6 +789,24 @@ extern "C"
         return install_tree(c, &v, bt.d_sx, bt.d_sy, bt.d_sz, bt.d_srow);
     }
 
+    int icp_hip_get_tree_info(icp_hip_ctx* c, icp_flat_tree* out)
+    {
+        if (!c || !out)
+            return fail(c, ICP_HIP_ERR_ARG, "icp_hip_get_tree_info: NULL argument");
+        if (!c->has_tree)
+            return fail(c, ICP_HIP_ERR_ARG, "icp_hip_get_tree_info: no tree on the device");
+        *out = icp_flat_tree{};
+        out->n_points = c->n_tree_points;
+        out->n_slots = c->tree.n_slots;
+        out->n_nodes = c->tree.n_nodes;
+        out->n_leaves = (uint32_t)c->leaf_info.count;
+        out->height = c->height;
+        out->capacity = c->capacity;
+        out->max_leaf_count = c->max_leaf;
+        out->root = c->tree.root;
+        return ICP_HIP_OK;
+    }
+
     int icp_hip_get_tree(icp_hip_ctx* c, icp_flat_tree** out)
     {
         if (!c || !out)

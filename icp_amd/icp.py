@@ -25,7 +25,7 @@ def _progress_printer(max_iters):
 
 def icp(m, p, iterations: int = 200, threshold: float = 1e-5, vp_threshold: int = 256, *,
         device_id: int = -1, quiet: bool = True, shard=None, allreduce=None, comm=None,
-        return_info: bool = False):
+        return_info: bool = False, tree_on: str = "device"):
     """Register cloud ``p`` onto reference cloud ``m`` on one MI355X.
 
     Returns ``(T, new_p)``: the 4x4 row-major transform mapping the original ``p`` onto ``m``
@@ -35,29 +35,40 @@ def icp(m, p, iterations: int = 200, threshold: float = 1e-5, vp_threshold: int 
     Sharded runs (one process per GPU): pass ``shard=(begin, end)`` to own rows [begin, end) of
     ``p`` and either ``allreduce`` (callable summing a float64 array in place over ranks) or
     ``comm=(n_ranks, rank, unique_id)`` for RCCL.  ``new_p`` is then the moved shard.
+
+    ``tree_on``: "device" builds the VP-tree in HBM (icp_hip_build_tree), "host" builds it with
+    icp_hip_tree_build and uploads it; the two trees are identical.
     """
     m = capi._pts(m)
     p = capi._pts(p)
     if len(m) == 0 or len(p) == 0:
         raise ValueError("icp: empty point cloud")
+    if tree_on not in ("device", "host"):
+        raise ValueError("tree_on must be 'device' or 'host'")
     mu_m = capi.mean_host(m)                       # icp.cc:106
-    tree = capi.FlatTree(capi.center_host(m, mu_m), vp_threshold)  # icp.cc:108
-    try:
-        with capi.Context(device_id) as ctx:
-            ctx.set_tree(tree)
-            b, e = (0, len(p)) if shard is None else shard
-            ctx.set_queries(p[b:e], n_total=len(p))
-            if comm is not None:
-                ctx.comm_init_rank(*comm)
-            elif allreduce is not None:
-                ctx.set_allreduce(allreduce)
-            T, iters, err = ctx.run(mu_m, iterations, threshold,
-                                    None if quiet else _progress_printer(iterations))
-            new_p = ctx.get_points()
-            info = dict(iterations=iters, error=err, timing=ctx.timing(), height=tree.height,
-                        n_nodes=tree.n_nodes, n_leaves=tree.n_leaves)
-    finally:
-        tree.close()
+    mc = capi.center_host(m, mu_m)                 # icp.cc:108
+    with capi.Context(device_id) as ctx:
+        if tree_on == "device":
+            ctx.build_tree(mc, vp_threshold)
+        else:
+            tree = capi.FlatTree(mc, vp_threshold)
+            try:
+                ctx.set_tree(tree)
+            finally:
+                tree.close()
+        del mc
+        b, e = (0, len(p)) if shard is None else shard
+        ctx.set_queries(p[b:e], n_total=len(p))
+        if comm is not None:
+            ctx.comm_init_rank(*comm)
+        elif allreduce is not None:
+            ctx.set_allreduce(allreduce)
+        T, iters, err = ctx.run(mu_m, iterations, threshold,
+                                None if quiet else _progress_printer(iterations))
+        new_p = ctx.get_points()
+        ti = ctx.tree_info()
+        info = dict(iterations=iters, error=err, timing=ctx.timing(), height=ti["height"],
+                    n_nodes=ti["n_nodes"], n_leaves=ti["n_leaves"])
     if return_info:
         return T, new_p, info
     return T, new_p
@@ -68,11 +79,7 @@ def closest(m_centered, queries, vp_threshold: int = 256, *, device_id: int = -1
 
     Returns dict(xyz, row, dist, kernel_ms).
     """
-    tree = capi.FlatTree(m_centered, vp_threshold)
-    try:
-        with capi.Context(device_id) as ctx:
-            ctx.set_tree(tree)
-            ctx.set_queries(queries)
-            return ctx.nn(np.zeros(3, np.float32))
-    finally:
-        tree.close()
+    with capi.Context(device_id) as ctx:
+        ctx.build_tree(m_centered, vp_threshold)
+        ctx.set_queries(queries)
+        return ctx.nn(np.zeros(3, np.float32))

@@ -140,6 +140,9 @@ int icp_hip_build_tree(icp_hip_ctx* ctx, const float* xyz_centered, uint64_t n, 
  * counterpart beyond the friend access of GPUVPTree (libcpu/libcpu/vp-tree.hh:8-17); used by the
  * tests and to cache a tree.  Free with icp_hip_tree_free. */
 int icp_hip_get_tree(icp_hip_ctx* ctx, icp_flat_tree** out);
+/* Scalar fields of the context's tree only (counts, height, capacity, root); every array pointer
+ * of *out is set to NULL.  Nothing is copied from the device. */
+int icp_hip_get_tree_info(icp_hip_ctx* ctx, icp_flat_tree* out);
 
 /* Upload this context's contiguous shard of the cloud to move ("p", icp.hh:20).
  * Replaces GPUMatrix::from_point_list (libgpu/libgpu/matrix.cu:95-103).

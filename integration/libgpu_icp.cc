@@ -21,11 +21,6 @@ namespace
 {
     static_assert(sizeof(libcpu::Point3D) == 3 * sizeof(float), "Point3D must be 3 packed floats");
 
-    struct Tree
-    {
-        icp_flat_tree* t = nullptr;
-        ~Tree() { icp_hip_tree_free(t); }
-    };
     struct Ctx
     {
         icp_hip_ctx* c = nullptr;
@@ -57,13 +52,13 @@ namespace libgpu
         libcpu::point_list centred(m.size());
         icp_hip_center_host(m_xyz, m.size(), mu_m, reinterpret_cast<float*>(centred.data()));
 
-        Tree tree;
-        check(icp_hip_tree_build(reinterpret_cast<const float*>(centred.data()), centred.size(),
-                                 vp_threshold, &tree.t),
-              nullptr); // icp.cu:141-142
         Ctx ctx;
         check(icp_hip_create(&ctx.c, -1), nullptr);
-        check(icp_hip_set_tree(ctx.c, tree.t), ctx.c);
+        // the reference builds the tree on the host and copies it node by node (icp.cu:141-142,
+        // vp-tree.cu:58-112); here the same tree is built in HBM
+        check(icp_hip_build_tree(ctx.c, reinterpret_cast<const float*>(centred.data()),
+                                 centred.size(), vp_threshold),
+              ctx.c);
         check(icp_hip_set_queries(ctx.c, p_xyz, p.size(), p.size()), ctx.c);
 
         float T[16];
