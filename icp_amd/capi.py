@@ -21,7 +21,7 @@ EXPORTS = [
     "icp_hip_tree_build", "icp_hip_tree_free", "icp_hip_tree_validate", "icp_hip_mean_host",
     "icp_hip_center_host", "icp_hip_alignment_host", "icp_hip_create", "icp_hip_destroy", "icp_hip_last_error",
     "icp_hip_last_global_error", "icp_hip_set_tree", "icp_hip_build_tree", "icp_hip_get_tree",
-    "icp_hip_get_tree_info",
+    "icp_hip_get_tree_info", "icp_hip_read_csv", "icp_hip_read_f32", "icp_hip_free_points",
     "icp_hip_set_queries", "icp_hip_nn",
     "icp_hip_set_allreduce", "icp_hip_comm_unique_id", "icp_hip_comm_init_rank", "icp_hip_run",
     "icp_hip_get_points", "icp_hip_get_timing", "icp_hip_get_nn_trace",
@@ -84,6 +84,11 @@ def load() -> C.CDLL:
     L.icp_hip_center_host.restype = None
     L.icp_hip_alignment_host.argtypes = [vp, vp, vp, vp]
     L.icp_hip_alignment_host.restype = None
+    f32pp = C.POINTER(C.POINTER(C.c_float))
+    L.icp_hip_read_csv.argtypes = [C.c_char_p] * 4 + [f32pp, C.POINTER(u64)]
+    L.icp_hip_read_f32.argtypes = [C.c_char_p, f32pp, C.POINTER(u64)]
+    L.icp_hip_free_points.argtypes = [C.POINTER(C.c_float)]
+    L.icp_hip_free_points.restype = None
     L.icp_hip_create.argtypes = [C.POINTER(vp), C.c_int]
     L.icp_hip_destroy.argtypes = [vp]
     L.icp_hip_destroy.restype = None
@@ -120,6 +125,28 @@ def _check(rc: int, ctx=None):
         L = load()
         msg = (L.icp_hip_last_error(ctx) if ctx else L.icp_hip_last_global_error()) or b""
         raise IcpHipError(rc, msg.decode(errors="replace"))
+
+
+def _take_points(ptr, n) -> np.ndarray:
+    try:
+        return np.ctypeslib.as_array(ptr, shape=(n.value, 3)).copy() if n.value else \
+            np.zeros((0, 3), np.float32)
+    finally:
+        load().icp_hip_free_points(ptr)
+
+
+def read_csv(path: str, x_field="Points_0", y_field="Points_1", z_field="Points_2") -> np.ndarray:
+    """libcpu::read_csv (point-3d.cc:105-134) with main's field names as defaults (main.cc:24-27)."""
+    ptr, n = C.POINTER(C.c_float)(), C.c_uint64()
+    _check(load().icp_hip_read_csv(os.fsencode(path), x_field.encode(), y_field.encode(),
+                                   z_field.encode(), C.byref(ptr), C.byref(n)))
+    return _take_points(ptr, n)
+
+
+def read_f32(path: str) -> np.ndarray:
+    ptr, n = C.POINTER(C.c_float)(), C.c_uint64()
+    _check(load().icp_hip_read_f32(os.fsencode(path), C.byref(ptr), C.byref(n)))
+    return _take_points(ptr, n)
 
 
 def mean_host(xyz) -> np.ndarray:

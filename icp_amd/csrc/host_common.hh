@@ -30,6 +30,11 @@ namespace icp_host
     void mean_host(const float* a, uint64_t n, float out[3]);
     void center_host(const float* a, uint64_t n, const float mu[3], float* out);
 
+    // loaders (io.cc): libcpu::read_csv restated (point-3d.cc:8-134) and a raw float32 reader
+    int read_csv(const char* path, const char* x_field, const char* y_field, const char* z_field,
+                 std::vector<float>& xyz, std::string& err);
+    int read_f32(const char* path, std::vector<float>& xyz, std::string& err);
+
     // 3x3 cross-covariance (row = P coordinate, col = Y coordinate) -> 4x4 rigid transform.
     // libcpu/libcpu/icp.cc:27-60 (find_alignment after find_covariance) + to_transformation :11-25.
     void alignment_from_covariance(const float H[9], const float mu_p[3], const float mu_m[3],

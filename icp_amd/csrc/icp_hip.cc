@@ -598,6 +598,49 @@ extern "C"
         icp_host::center_host(xyz, n, mu, out_xyz);
     }
 
+    static int hand_over(std::vector<float>& v, float** xyz_out, uint64_t* n_out, const char* who)
+    {
+        float* p = (float*)std::malloc(v.empty() ? 1 : v.size() * sizeof(float));
+        if (!p)
+            return fail(nullptr, ICP_HIP_ERR_NOMEM, std::string(who) + ": out of host memory");
+        if (!v.empty())
+            std::memcpy(p, v.data(), v.size() * sizeof(float));
+        *xyz_out = p;
+        *n_out = v.size() / 3;
+        return ICP_HIP_OK;
+    }
+
+    int icp_hip_read_csv(const char* path, const char* x_field, const char* y_field,
+                         const char* z_field, float** xyz_out, uint64_t* n_out)
+    {
+        if (!path || !x_field || !y_field || !z_field || !xyz_out || !n_out)
+            return fail(nullptr, ICP_HIP_ERR_ARG, "icp_hip_read_csv: NULL argument");
+        *xyz_out = nullptr;
+        *n_out = 0;
+        std::vector<float> v;
+        std::string err;
+        int rc = icp_host::read_csv(path, x_field, y_field, z_field, v, err);
+        if (rc != ICP_HIP_OK)
+            return fail(nullptr, rc, err);
+        return hand_over(v, xyz_out, n_out, "icp_hip_read_csv");
+    }
+
+    int icp_hip_read_f32(const char* path, float** xyz_out, uint64_t* n_out)
+    {
+        if (!path || !xyz_out || !n_out)
+            return fail(nullptr, ICP_HIP_ERR_ARG, "icp_hip_read_f32: NULL argument");
+        *xyz_out = nullptr;
+        *n_out = 0;
+        std::vector<float> v;
+        std::string err;
+        int rc = icp_host::read_f32(path, v, err);
+        if (rc != ICP_HIP_OK)
+            return fail(nullptr, rc, err);
+        return hand_over(v, xyz_out, n_out, "icp_hip_read_f32");
+    }
+
+    void icp_hip_free_points(float* xyz) { std::free(xyz); }
+
     void icp_hip_alignment_host(const float H[9], const float mu_p[3], const float mu_m[3],
                                 float T_out[16])
     {

@@ -101,6 +101,17 @@ void icp_hip_mean_host(const float* xyz, uint64_t n, float mu_out[3]);
 /* libcpu::subtract(list, point) (point-3d.cc:194-210). */
 void icp_hip_center_host(const float* xyz, uint64_t n, const float mu[3], float* out_xyz);
 
+/* Loaders.  icp_hip_read_csv replaces libcpu::read_csv (libcpu/libcpu/point-3d.cc:8-134) as main
+ * calls it (main/main/main.cc:24-27 with "Points_0","Points_1","Points_2"): header lookup by field
+ * name, other columns ignored, std::stof per token; the reference's runtime_error texts come back
+ * through icp_hip_last_global_error.  icp_hip_read_f32 reads raw float32 x,y,z triples (no
+ * reference counterpart: text parsing would dwarf the registration at 64M points).
+ * *xyz_out is malloc'ed (n x 3 floats, Point3D layout); free it with icp_hip_free_points. */
+int icp_hip_read_csv(const char* path, const char* x_field, const char* y_field,
+                     const char* z_field, float** xyz_out, uint64_t* n_out);
+int icp_hip_read_f32(const char* path, float** xyz_out, uint64_t* n_out);
+void icp_hip_free_points(float* xyz);
+
 /* Rigid-transform solve on the host: 3x3 cross-covariance H (row-major, row = coordinate of the
  * centred moving cloud, column = coordinate of its matched reference points) -> row-major 4x4
  * [r t; 0 0 0 1] with r = V U^T (no reflection fix) and t = mu_m - r mu_p.
