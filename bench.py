@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--capacity", type=int, default=256)
     ap.add_argument("--angle", type=float, default=None,
                     help="rigid-motion angle in degrees (default 1.0 at <= 8M points, 0.25 above)")
-    ap.add_argument("--cpu-sample", type=int, default=2_000_000,
+    ap.add_argument("--cpu-sample", type=int, default=64_000_000,
                     help="queries of the CPU-baseline sample (0 disables the baseline)")
     return ap.parse_args()
 
