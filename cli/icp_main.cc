@@ -209,19 +209,14 @@ int main(int argc, char* argv[])
     float T[16];
     std::vector<float> new_p(3 * p.n);
     {
-        float mu_m[3];
-        icp_hip_mean_host(q.xyz, q.n, mu_m);
-        std::vector<float> centred(3 * q.n);
-        icp_hip_center_host(q.xyz, q.n, mu_m, centred.data());
         Ctx ctx;
         check(icp_hip_create(&ctx.c, -1), nullptr);
-        check(icp_hip_build_tree(ctx.c, centred.data(), q.n, o.capacity), ctx.c);
-        check(icp_hip_set_queries(ctx.c, p.xyz, p.n, p.n), ctx.c);
         uint64_t iters = 0;
         float err = 0.f;
-        check(icp_hip_run(ctx.c, mu_m, o.iterations, o.error, T, &iters, &err, progress, nullptr),
+        // libgpu::icp(q, p, iterations, error, capacity) (main.cc:31-34)
+        check(icp_hip_icp(ctx.c, q.xyz, q.n, p.xyz, p.n, o.iterations, o.error, o.capacity, T,
+                          new_p.data(), &iters, &err, progress, nullptr),
               ctx.c);
-        check(icp_hip_get_points(ctx.c, new_p.data()), ctx.c);
     }
     gettimeofday(&end, nullptr);
     const long start_ms = start.tv_sec * 1000 + start.tv_usec / 1000;

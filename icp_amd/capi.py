@@ -24,7 +24,7 @@ EXPORTS = [
     "icp_hip_get_tree_info", "icp_hip_read_csv", "icp_hip_read_f32", "icp_hip_free_points",
     "icp_hip_set_queries", "icp_hip_nn",
     "icp_hip_set_allreduce", "icp_hip_comm_unique_id", "icp_hip_comm_init_rank", "icp_hip_run",
-    "icp_hip_get_points", "icp_hip_get_timing", "icp_hip_get_nn_trace",
+    "icp_hip_get_points", "icp_hip_get_timing", "icp_hip_get_nn_trace", "icp_hip_icp",
 ]
 
 
@@ -107,6 +107,8 @@ def load() -> C.CDLL:
     L.icp_hip_run.argtypes = [vp, vp, u64, C.c_float, vp, C.POINTER(u64), C.POINTER(C.c_float),
                               PROGRESS_FN, vp]
     L.icp_hip_get_points.argtypes = [vp, vp]
+    L.icp_hip_icp.argtypes = [vp, vp, u64, vp, u64, u64, C.c_float, u32, vp, vp, C.POINTER(u64),
+                              C.POINTER(C.c_float), PROGRESS_FN, vp]
     L.icp_hip_get_timing.argtypes = [vp, C.POINTER(TimingStruct)]
     L.icp_hip_get_nn_trace.argtypes = [vp, vp, u64, C.POINTER(u64)]
     _lib = L
@@ -330,6 +332,21 @@ class Context:
         _check(self._L.icp_hip_run(self._h, mu.ctypes.data, int(max_iters), float(threshold),
                                    T.ctypes.data, C.byref(it), C.byref(err), cb, None), self._h)
         return T.reshape(4, 4), it.value, err.value
+
+    def icp(self, m, p, iterations: int, threshold: float, vp_threshold: int, progress=None):
+        """libgpu::icp in one call (icp_hip_icp): returns (T, new_p, iterations, error)."""
+        m, p = _pts(m), _pts(p)
+        T = np.zeros(16, np.float32)
+        new_p = np.empty_like(p)
+        it, err = C.c_uint64(), C.c_float()
+        cb = C.cast(None, PROGRESS_FN) if progress is None else \
+            PROGRESS_FN(lambda i, mx, e, _u: progress(i, mx, e))
+        _check(self._L.icp_hip_icp(self._h, m.ctypes.data, len(m), p.ctypes.data, len(p),
+                                   int(iterations), float(threshold), int(vp_threshold),
+                                   T.ctypes.data, new_p.ctypes.data, C.byref(it), C.byref(err),
+                                   cb, None), self._h)
+        self.n_local = len(p)
+        return T.reshape(4, 4), new_p, it.value, err.value
 
     def get_points(self) -> np.ndarray:
         out = np.empty((self.n_local, 3), np.float32)

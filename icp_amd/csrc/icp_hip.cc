@@ -80,29 +80,43 @@ namespace
         }
     } g_rccl;
 
+    // Device array that is kept across calls: alloc(n) reuses the allocation when it is large
+    // enough (a context that is reused for the next registration allocates nothing new).
     template <class T>
     struct DevBuf
     {
         T* p = nullptr;
-        size_t count = 0;
+        size_t count = 0; // logical size
+        size_t cap = 0;   // allocated entries
         hipError_t alloc(size_t n)
         {
+            if (n != 0 && p && n <= cap)
+            {
+                count = n;
+                return hipSuccess;
+            }
             release();
             if (n == 0)
                 return hipSuccess;
             hipError_t e = hipMalloc((void**)&p, n * sizeof(T));
             if (e == hipSuccess)
-                count = n;
+                count = cap = n;
             else
                 p = nullptr;
             return e;
+        }
+        void adopt(T* ptr, size_t n) // take over an allocation made elsewhere
+        {
+            release();
+            p = ptr;
+            count = cap = n;
         }
         void release()
         {
             if (p)
                 (void)hipFree(p);
             p = nullptr;
-            count = 0;
+            count = cap = 0;
         }
     };
 } // namespace
@@ -136,12 +150,14 @@ struct icp_hip_ctx
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint32_t tile_blocks = 0;   // resident nn_tile_kernel workgroups on this device (multiple of 8)
     bool force_deep = false;    // ICP_HIP_NN_KERNEL=deep: always run nn_cov_kernel
+    int tree_build_on = 0;      // ICP_HIP_TREE_BUILD: 0 auto (by size), 1 device, 2 host
     // nn_tile_kernel work queue / per-chunk sums / overflow stack (sized by prepare_tile)
     DevBuf<uint32_t> queue;
     DevBuf<double> chunk_sums;
     DevBuf<uint2> spill;
     DevBuf<unsigned long long> stats; // ICP_HIP_TILE_STATS=1: event counters, printed per pass
     uint32_t chunk_batches = 1, n_chunks = 0, tile_grid_blocks = 8, spill_levels = 0;
+    uint32_t batch_queries = 64; // queries per wave-batch of nn_tile_kernel (prepare_tile)
     bool tile_ready = false;
     uint32_t tile_cut = 1; // ICP_HIP_TILE_CUT overrides (0 = run the node phase to the end)
 
@@ -259,7 +275,21 @@ namespace
         c->tile_ready = false;
         if (!c->has_tree || !c->has_queries || c->n_local == 0)
             return ICP_HIP_OK;
-        const uint64_t batches = (c->n_local + 63) / 64;
+        // queries per batch: 64 (one per lane) when that fills every resident wave slot; a
+        // smaller shard is cut into narrower batches (32/16/8 queries per wave) so that all
+        // SIMDs get work and each wave's serial chain of bucket scans is shorter
+        uint32_t bq = 64;
+        {
+            const char* env = std::getenv("ICP_HIP_BATCH_QUERIES");
+            const int forced = env ? std::atoi(env) : 0;
+            if (forced == 64 || forced == 32 || forced == 16 || forced == 8)
+                bq = (uint32_t)forced;
+            else
+                while (bq > 8 && (c->n_local + bq - 1) / bq < (uint64_t)c->tile_blocks * 4)
+                    bq >>= 1;
+        }
+        c->batch_queries = bq;
+        const uint64_t batches = (c->n_local + bq - 1) / bq;
         // every workgroup resident; at least one batch per wave
         uint64_t g = (batches + 3) / 4;
         if (g > c->tile_blocks)
@@ -300,8 +330,8 @@ namespace
         else
         {
             a.grid = c->tile_grid_blocks;
-            TileLaunch q{c->chunk_batches, c->chunk_sums.p, c->queue.p, c->spill.p, c->stats.p,
-                         c->tile_cut};
+            TileLaunch q{c->chunk_batches, c->batch_queries, c->chunk_sums.p, c->queue.p,
+                         c->spill.p, c->stats.p, c->tile_cut};
             if (c->stats.p)
                 HIP_TRY(c, hipMemsetAsync(c->stats.p, 0, 8 * sizeof(unsigned long long), c->stream));
             HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
@@ -496,14 +526,10 @@ namespace
         };
         if (d_sx)
         {
-            c->sx.release();
-            c->sy.release();
-            c->sz.release();
-            c->srow.release();
-            c->sx.p = d_sx, c->sx.count = ns + slack;
-            c->sy.p = d_sy, c->sy.count = ns + slack;
-            c->sz.p = d_sz, c->sz.count = ns + slack;
-            c->srow.p = d_srow, c->srow.count = ns;
+            c->sx.adopt(d_sx, ns + slack);
+            c->sy.adopt(d_sy, ns + slack);
+            c->sz.adopt(d_sz, ns + slack);
+            c->srow.adopt(d_srow, ns);
         }
         else
             ok = ok && up_slots(c->sx, t->slot_x) && up_slots(c->sy, t->slot_y) &&
@@ -699,6 +725,10 @@ extern "C"
             c->tile_blocks = (uint32_t)blocks;
             const char* env = std::getenv("ICP_HIP_NN_KERNEL");
             c->force_deep = env && std::strcmp(env, "deep") == 0;
+            const char* tb = std::getenv("ICP_HIP_TREE_BUILD");
+            c->tree_build_on = !tb ? 0 : std::strcmp(tb, "device") == 0 ? 1
+                                       : std::strcmp(tb, "host") == 0   ? 2
+                                                                        : 0;
             const char* cut = std::getenv("ICP_HIP_TILE_CUT");
             if (cut)
                 c->tile_cut = (uint32_t)std::atoi(cut);
@@ -779,6 +809,19 @@ extern "C"
                         "(vp-tree.cc:114: empty inside set on 2-point nodes)");
         DeviceGuard g(c->device);
         c->has_tree = false;
+        // A small cloud is built by the host builder (same tree, bit for bit) and uploaded: the
+        // level-by-level device build costs ~0.1 ms of launches per level whatever the size.
+        constexpr uint64_t kHostBuildBelow = 8192;
+        if (c->tree_build_on == 2 || (c->tree_build_on == 0 && n < kHostBuildBelow))
+        {
+            icp_flat_tree* t = nullptr;
+            int rc = icp_hip_tree_build(xyz_centered, n, capacity, &t);
+            if (rc != ICP_HIP_OK)
+                return fail(c, rc, g_error);
+            rc = install_tree(c, t, nullptr, nullptr, nullptr, nullptr);
+            icp_hip_tree_free(t);
+            return rc;
+        }
         DevBuf<float> cloud;
         HIP_TRY(c, cloud.alloc(3 * n));
         struct Free
@@ -1197,6 +1240,44 @@ extern "C"
                                   hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         return ICP_HIP_OK;
+    }
+
+    int icp_hip_icp(icp_hip_ctx* c, const float* m_xyz, uint64_t n_m, const float* p_xyz,
+                    uint64_t n_p, uint64_t iterations, float threshold, uint32_t vp_threshold,
+                    float T_out[16], float* new_p_xyz, uint64_t* iters_done, float* final_error,
+                    icp_hip_progress_fn progress, void* user)
+    {
+        if (!c)
+            return fail(nullptr, ICP_HIP_ERR_ARG, "icp_hip_icp: ctx is NULL");
+        if (!m_xyz || !p_xyz || !T_out)
+            return fail(c, ICP_HIP_ERR_ARG, "icp_hip_icp: NULL argument");
+        if (n_m == 0 || n_p == 0)
+            return fail(c, ICP_HIP_ERR_ARG, "icp_hip_icp: empty point cloud");
+        // mu_m = mean(m); the tree is built over m - mu_m (icp.cc:106-108, icp.cu:139-142)
+        float mu_m[3];
+        std::vector<float> centred;
+        try
+        {
+            centred.resize(3 * (size_t)n_m);
+        }
+        catch (const std::bad_alloc&)
+        {
+            return fail(c, ICP_HIP_ERR_NOMEM, "icp_hip_icp: out of host memory");
+        }
+        icp_host::mean_host(m_xyz, n_m, mu_m);
+        icp_host::center_host(m_xyz, n_m, mu_m, centred.data());
+        int rc = icp_hip_build_tree(c, centred.data(), n_m, vp_threshold);
+        if (rc != ICP_HIP_OK)
+            return rc;
+        std::vector<float>().swap(centred);
+        if ((rc = icp_hip_set_queries(c, p_xyz, n_p, n_p)) != ICP_HIP_OK)
+            return rc;
+        if ((rc = icp_hip_run(c, mu_m, iterations, threshold, T_out, iters_done, final_error,
+                              progress, user)) != ICP_HIP_OK)
+            return rc;
+        if (new_p_xyz)
+            rc = icp_hip_get_points(c, new_p_xyz);
+        return rc;
     }
 
     int icp_hip_get_nn_trace(icp_hip_ctx* c, float* ms_out, uint64_t capacity, uint64_t* count)

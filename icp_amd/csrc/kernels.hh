@@ -70,7 +70,11 @@ namespace icp_dev
     constexpr uint32_t kQueueWords = 256; // 8 queue heads, one per 128-byte line
     struct TileLaunch
     {
-        uint32_t chunk_batches; // 64-query batches per chunk (1..8)
+        uint32_t chunk_batches; // batches per chunk (1..8)
+        uint32_t batch_queries; // queries per batch = active lanes per wave: 64, 32, 16 or 8.
+                                // 64 for large shards; a shard too small to fill the chip is cut
+                                // into narrower batches so that every SIMD gets waves, and the
+                                // idle lanes join the bucket scans as extra parts
         double* chunk_sums;     // [n_chunks][kCovSums] or null
         uint32_t* queue;        // kQueueWords words, zeroed by the launch
         uint2* spill;           // [max(0, height - stack entries)][grid * 256] or null

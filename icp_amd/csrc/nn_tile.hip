@@ -280,7 +280,8 @@ namespace icp_dev
                            const uint32_t* __restrict__ perm, double* __restrict__ chunk_sums,
                            uint32_t* __restrict__ queue, uint2* __restrict__ spill,
                            uint32_t n_batches, uint32_t chunk_batches, uint32_t n_chunks,
-                           uint32_t cut, unsigned long long* __restrict__ stats)
+                           uint32_t cut, uint32_t batch_queries,
+                           unsigned long long* __restrict__ stats)
         {
             __shared__ WaveLds s_w[kWavesPerBlock];
             // wave-level event counts of the diagnostic build (ICP_HIP_TILE_STATS=1)
@@ -339,8 +340,8 @@ namespace icp_dev
             {
                 if (STATS)
                     st_batch += 1u;
-                const uint32_t i = b * kWave + (uint32_t)lane;
-                const bool valid = i < n;
+                const uint32_t i = b * batch_queries + (uint32_t)lane;
+                const bool valid = (uint32_t)lane < batch_queries && i < n;
                 float qx = 0.f, qy = 0.f, qz = 0.f;
                 if (valid)
                 {
@@ -668,7 +669,10 @@ namespace icp_dev
             return hipErrorInvalidValue;
         if (a.height > (uint32_t)kStackK && !q.spill)
             return hipErrorInvalidValue;
-        const uint32_t n_batches = (a.n + kWave - 1) / kWave;
+        const uint32_t bq = q.batch_queries;
+        if (bq != 64u && bq != 32u && bq != 16u && bq != 8u)
+            return hipErrorInvalidValue;
+        const uint32_t n_batches = (a.n + bq - 1) / bq;
         const uint32_t n_chunks = (n_batches + q.chunk_batches - 1) / q.chunk_batches;
         hipError_t e = hipMemsetAsync(q.queue, 0, kQueueWords * sizeof(uint32_t), s);
         if (e != hipSuccess)
@@ -677,12 +681,12 @@ namespace icp_dev
             hipLaunchKernelGGL(nn_tile_kernel<true>, dim3(a.grid), dim3(kBlock), 0, s, a.tree, a.px,
                                a.py, a.pz, a.mu[0], a.mu[1], a.mu[2], a.n, a.yx, a.yy, a.yz,
                                a.row_out, a.dist_out, a.perm, q.chunk_sums, q.queue, q.spill,
-                               n_batches, q.chunk_batches, n_chunks, q.cut, q.stats);
+                               n_batches, q.chunk_batches, n_chunks, q.cut, bq, q.stats);
         else
             hipLaunchKernelGGL(nn_tile_kernel<false>, dim3(a.grid), dim3(kBlock), 0, s, a.tree, a.px,
                                a.py, a.pz, a.mu[0], a.mu[1], a.mu[2], a.n, a.yx, a.yy, a.yz,
                                a.row_out, a.dist_out, a.perm, q.chunk_sums, q.queue, q.spill,
-                               n_batches, q.chunk_batches, n_chunks, q.cut, nullptr);
+                               n_batches, q.chunk_batches, n_chunks, q.cut, bq, nullptr);
         return hipGetLastError();
     }
 } // namespace icp_dev

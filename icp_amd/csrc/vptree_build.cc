@@ -215,7 +215,7 @@ namespace icp_host
             b.perm[i] = (uint32_t)i;
 
         int32_t root = 0;
-#pragma omp parallel
+#pragma omp parallel if (n > (1u << 14))
 #pragma omp single
         root = b.build(0, n);
 
@@ -332,7 +332,7 @@ namespace icp_host
         T->slot_y.assign(slots, inf);
         T->slot_z.assign(slots, inf);
         T->slot_row.assign(slots, 0xFFFFFFFFu);
-#pragma omp parallel for schedule(dynamic, 64)
+#pragma omp parallel for schedule(dynamic, 64) if (n_leaves > 1024u)
         for (uint32_t l = 0; l < n_leaves; ++l)
         {
             const TmpLeaf& lf = b.leaves[old_of_new[l]];
@@ -499,7 +499,8 @@ namespace icp_host
     // libcpu::subtract(list, point), point-3d.cc:194-210
     void center_host(const float* a, uint64_t n, const float mu[3], float* out)
     {
-#pragma omp parallel for
+        // small clouds stay on the calling thread (waking the team costs more than the loop)
+#pragma omp parallel for if (n > (1u << 16))
         for (uint64_t i = 0; i < n; ++i)
         {
             out[3 * i] = a[3 * i] - mu[0];

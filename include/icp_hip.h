@@ -145,7 +145,10 @@ int icp_hip_set_tree(icp_hip_ctx* ctx, const icp_flat_tree* tree);
  * reference cloud centred on its mean) is uploaded once and the tree is built level by level in
  * HBM, straight into the layout the kernels read.  The tree is the one icp_hip_tree_build makes
  * (hence the reference's), bit for bit; icp_hip_get_tree returns it for inspection.  Same error
- * conventions as icp_hip_tree_build (ICP_HIP_ERR_DEGENERATE where the reference is undefined). */
+ * conventions as icp_hip_tree_build (ICP_HIP_ERR_DEGENERATE where the reference is undefined).
+ * Clouds below 8192 points are built by icp_hip_tree_build and uploaded instead (the per-level
+ * launches cost more than the serial build there); ICP_HIP_TREE_BUILD=device|host in the
+ * environment at icp_hip_create forces one or the other. */
 int icp_hip_build_tree(icp_hip_ctx* ctx, const float* xyz_centered, uint64_t n, uint32_t capacity);
 /* Host copy of the context's tree in the flat layout (whichever way it got there).  No reference
  * counterpart beyond the friend access of GPUVPTree (libcpu/libcpu/vp-tree.hh:8-17); used by the
@@ -198,6 +201,22 @@ int icp_hip_run(icp_hip_ctx* ctx, const float mu_m[3], uint64_t max_iters, float
 
 /* Moved shard, same order as given to icp_hip_set_queries (icp.cu:160 to_point_list). */
 int icp_hip_get_points(icp_hip_ctx* ctx, float* xyz_aos);
+
+/* The whole registration in one call on one GPU: replaces libgpu::icp itself
+ * (libgpu/libgpu/icp.hh:19-21, icp.cu:128-161) as main and bench call it (main/main/main.cc:31-34,
+ * bench/bench/benchmark.cc:78) -- mu_m = mean(m), tree over m - mu_m (vp_threshold = leaf capacity),
+ * the loop of icp_hip_run over the whole of p, the moved cloud back in input order.  m_xyz and
+ * p_xyz are borrowed and never written; T_out receives the 4x4, new_p_xyz (n_p x 3 floats, may be
+ * NULL) the moved cloud (icp.cu:160).  `ctx` is the context to run on: its tree, shard and
+ * buffers are replaced, and a context that is reused for the next call keeps its device buffers
+ * when they are large enough (the reference allocates and frees everything inside each call,
+ * matrix.cu:6-17; a caller that wants exactly that creates and destroys the context around the
+ * call).  Errors: status + icp_hip_last_error(ctx), e.g. ICP_HIP_ERR_DEGENERATE where the
+ * reference's tree build is undefined behaviour. */
+int icp_hip_icp(icp_hip_ctx* ctx, const float* m_xyz, uint64_t n_m, const float* p_xyz,
+                uint64_t n_p, uint64_t iterations, float threshold, uint32_t vp_threshold,
+                float T_out[16], float* new_p_xyz, uint64_t* iters_done, float* final_error,
+                icp_hip_progress_fn progress, void* user);
 
 /* Phase timers accumulated since the last icp_hip_set_queries (HIP events on the context's
  * stream; the reference has only gettimeofday around icp(), main.cc:29-40). */

@@ -47,28 +47,21 @@ namespace libgpu
         const float* m_xyz = reinterpret_cast<const float*>(m.data());
         const float* p_xyz = reinterpret_cast<const float*>(p.data());
 
-        float mu_m[3];
-        icp_hip_mean_host(m_xyz, m.size(), mu_m); // icp.cc:106
-        libcpu::point_list centred(m.size());
-        icp_hip_center_host(m_xyz, m.size(), mu_m, reinterpret_cast<float*>(centred.data()));
-
+        // device state lives exactly as long as the call, like the reference's RAII GPUMatrix /
+        // GPUVPTree (matrix.cu:13-17, vp-tree.cu:12-16); a caller that registers many clouds can
+        // keep one context alive instead (icp_hip_icp reuses its buffers)
         Ctx ctx;
         check(icp_hip_create(&ctx.c, -1), nullptr);
-        // the reference builds the tree on the host and copies it node by node (icp.cu:141-142,
-        // vp-tree.cu:58-112); here the same tree is built in HBM
-        check(icp_hip_build_tree(ctx.c, reinterpret_cast<const float*>(centred.data()),
-                                 centred.size(), vp_threshold),
-              ctx.c);
-        check(icp_hip_set_queries(ctx.c, p_xyz, p.size(), p.size()), ctx.c);
-
         float T[16];
         uint64_t iters = 0;
         float error = 0;
-        check(icp_hip_run(ctx.c, mu_m, iterations, threshold, T, &iters, &error, progress, nullptr),
-              ctx.c);
-
         libcpu::point_list new_p(p.size());
-        check(icp_hip_get_points(ctx.c, reinterpret_cast<float*>(new_p.data())), ctx.c);
+        // mean(m), the tree over m - mean(m) (built in HBM; the reference builds it on the host
+        // and copies it node by node, icp.cu:141-142, vp-tree.cu:58-112), the loop, the download
+        check(icp_hip_icp(ctx.c, m_xyz, m.size(), p_xyz, p.size(), iterations, threshold,
+                          vp_threshold, T, reinterpret_cast<float*>(new_p.data()), &iters, &error,
+                          progress, nullptr),
+              ctx.c);
 
         utils::Matrix<float> transformation(4, 4);
         for (size_t i = 0; i < 4; ++i)

@@ -113,3 +113,28 @@ def test_synthetic_1m_recovers_known_transform(oracle):
     cpu = oracle.icp(m, p, 50, 1e-5, 256)
     assert np.abs(T - cpu["T"]).max() <= 2e-5
     assert abs(info["iterations"] - cpu["iterations"]) <= 1
+
+
+def test_one_call_entry_point_and_context_reuse(clouds):
+    """icp_hip_icp (libgpu::icp in one call, icp.cu:128-161) equals the step-by-step sequence bit
+    for bit, also on a context that is reused: horse, then the smaller cow (buffers kept from the
+    larger call), then horse again."""
+    import icp_amd
+    from icp_amd import capi
+    ref = {}
+    for name, tr, cap in (("horse", "horse_tr2", 256), ("cow", "cow_tr2", 32)):
+        ref[name] = icp_amd.icp(clouds[f"{name}_ref"], clouds[tr], 200, 1e-5, cap, return_info=True)
+    with capi.Context() as ctx:
+        for name, tr, cap in (("horse", "horse_tr2", 256), ("cow", "cow_tr2", 32),
+                              ("horse", "horse_tr2", 256)):
+            T, new_p, iters, err = ctx.icp(clouds[f"{name}_ref"], clouds[tr], 200, 1e-5, cap)
+            want_T, want_p, info = ref[name]
+            assert iters == info["iterations"] and err == info["error"]
+            assert (bits(T) == bits(want_T)).all()
+            assert (bits(new_p) == bits(want_p)).all()
+        # errors come back as a status + message, and the context stays usable
+        with pytest.raises(capi.IcpHipError) as e:
+            ctx.icp(clouds["cow_ref"], clouds["cow_tr1"], 200, 1e-5, 2)
+        assert e.value.status == 2  # capacity <= 2: undefined behaviour in the reference
+        T, new_p, iters, err = ctx.icp(clouds["cow_ref"], clouds["cow_tr2"], 200, 1e-5, 32)
+        assert (bits(T) == bits(ref["cow"][0])).all()

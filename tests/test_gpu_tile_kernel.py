@@ -141,3 +141,24 @@ def test_run_is_bitwise_reproducible():
     assert (bits(a[0]) == bits(b[0])).all()
     assert (bits(a[1]) == bits(b[1])).all()
     assert a[2]["error"] == b[2]["error"]
+
+
+@pytest.mark.parametrize("n,cap,angle", [(48_000, 32, 6.0), (48_000, 256, 2.0), (700, 16, 10.0)])
+def test_batch_widths_agree(oracle, n, cap, angle):
+    """A shard too small to fill the chip runs 8/16/32 queries per wave instead of 64 (idle lanes
+    join the bucket scans): every width gives the reference's answers, and the work counters of
+    the reference traversal do not depend on it."""
+    from icp_amd import capi, synth
+    m = synth.cloud(n, seed=n + cap)
+    p = synth.apply_fp32(m, synth.ground_truth(angle))
+    mc = capi.center_host(m, capi.mean_host(m))
+    mu_p = oracle.mean(p)
+    want = oracle.tree_closest(oracle.tree_build(cap, mc), oracle.subtract(p, mu_p))
+    tree = capi.FlatTree(mc, cap)
+    runs = [_nn(capi, tree, p, mu_p, {"ICP_HIP_BATCH_QUERIES": str(w)}) for w in (64, 32, 16, 8)]
+    for r in runs:
+        _same(r, want)
+        assert r["timing"]["nodes_visited"] == runs[0]["timing"]["nodes_visited"]
+        assert r["timing"]["points_scanned"] == runs[0]["timing"]["points_scanned"]
+    _same(_nn(capi, tree, p, mu_p), want)  # the width the library picks by itself
+    tree.close()

@@ -9,6 +9,13 @@ from conftest import bits
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def device_build(monkeypatch):
+    """icp_hip_build_tree hands clouds below 8192 points to the host builder; here the device
+    builder is the thing under test (the library reads the variable at icp_hip_create)."""
+    monkeypatch.setenv("ICP_HIP_TREE_BUILD", "device")
+
 FLOAT_FIELDS = ["node_cx", "node_cy", "node_cz", "node_radius", "slot_x", "slot_y", "slot_z"]
 INT_FIELDS = ["node_inside", "node_outside", "node_parent", "node_row", "leaf_begin", "leaf_count",
               "slot_row"]
@@ -108,3 +115,21 @@ def test_registration_on_a_device_built_tree(clouds, oracle):
             res.append((T.copy(), it, err))
     assert res[0][1] == res[1][1] == 16
     assert (bits(res[0][0]) == bits(res[1][0])).all() and res[0][2] == res[1][2]
+
+
+def test_small_clouds_take_the_host_builder_and_give_the_same_tree(clouds, monkeypatch):
+    from icp_amd import capi
+    mc = centred(capi, clouds["cow_ref"])
+    trees = []
+    for mode in ("device", "host", None):
+        if mode is None:
+            monkeypatch.delenv("ICP_HIP_TREE_BUILD")
+        else:
+            monkeypatch.setenv("ICP_HIP_TREE_BUILD", mode)
+        with capi.Context() as ctx:
+            ctx.build_tree(mc, 32)
+            trees.append(ctx.get_tree())
+    same_tree(trees[0], trees[1])
+    same_tree(trees[0], trees[2])
+    for t in trees:
+        t.close()
