@@ -352,6 +352,14 @@ namespace icp_dev
                 }
                 int node = t.root, prev = 0;
                 int mode = tDescend;
+                // The current descent chain (from the root, or from the far child of `ret_node`):
+                // `chain_lb` is a lower bound of min |radius - d| over its nodes and `chain_d2` the
+                // smallest squared centre distance.  If the bucket at its end answers with a
+                // distance below chain_lb, every prune test on the way back up passes
+                // (vp-tree.cc:152) and no centre is closer (:154): the lane jumps straight back to
+                // `ret_node` (or is done) instead of climbing level by level.
+                int ret_node = -1, top = t.root;
+                float chain_lb = __int_as_float(0x7f800000), chain_d2 = chain_lb;
                 uint32_t sp = 0, ovf = 0;
                 uint32_t n_int = 0, n_pts = 0; // work counters of this query
                 float rd = 0.f;
@@ -396,6 +404,18 @@ namespace icp_dev
                             n_int += (mode == tDescend) ? 1u : 0u;
                             const float d2 = sq_dist(qx, qy, qz, N.cx, N.cy, N.cz);
                             const bool in_near = d2 < N.thr; // sqrtf(d2) < N.r (:147-148)
+                            if (mode == tDescend)
+                            {
+                                // v_sqrt_f32 (1 ulp) instead of the rounded sqrtf: the slack
+                                // covers it five times over; a bound that is too small only
+                                // sends the lane the long way round
+                                const float da = __builtin_amdgcn_sqrtf(d2);
+                                const float lb = __fsub_rn(
+                                    fabsf(__fsub_rn(N.r, da)),
+                                    __fadd_rn(__fmul_rn(__fadd_rn(da, N.r), 0x1p-20f), 1e-18f));
+                                chain_lb = fminf(chain_lb, lb);
+                                chain_d2 = fminf(chain_d2, d2);
+                            }
                             const int nearc = in_near ? N.inside : N.outside;
                             const int farc = in_near ? N.outside : N.inside;
                             int go = nearc;
@@ -425,6 +445,9 @@ namespace icp_dev
                                         sp += 1u;
                                         go = farc; // :160
                                         up = false;
+                                        ret_node = node; // a new chain starts at the far child
+                                        top = farc;
+                                        chain_lb = chain_d2 = __int_as_float(0x7f800000);
                                     }
                                 }
                                 else
@@ -571,12 +594,26 @@ namespace icp_dev
                         {
                             rd = r;
                             rid = win;
+                            // r * r is within 2 ulps of every d2 whose root is r
+                            if (r < chain_lb && chain_d2 > __fmul_rn(__fmul_rn(r, r), 1.000002f))
+                            {
+                                node = ret_node;
+                                prev = top;
+                            }
                             mode = node < 0 ? tDone : tReturn;
                         }
                     }
                     if (mode == tServed)
                     {
-                        rd = sqrtf(rd);
+                        const float m = rd; // squared distance of the bucket's answer
+                        rd = sqrtf(m);
+                        // no centre of the chain is strictly closer: d2_k > m (1 + 1e-6) gives
+                        // sqrtf(d2_k) >= sqrtf(m)
+                        if (rd < chain_lb && chain_d2 > __fmul_rn(m, 1.000001f))
+                        {
+                            node = ret_node;
+                            prev = top;
+                        }
                         mode = node < 0 ? tDone : tReturn;
                     }
                 }

@@ -162,3 +162,28 @@ def test_batch_widths_agree(oracle, n, cap, angle):
         assert r["timing"]["points_scanned"] == runs[0]["timing"]["points_scanned"]
     _same(_nn(capi, tree, p, mu_p), want)  # the width the library picks by itself
     tree.close()
+
+
+@pytest.mark.parametrize("ulps", [1, 8, 200])
+def test_queries_a_few_ulps_from_tree_points(oracle, ulps):
+    """The kernel skips the way back up when the bucket's answer is closer than every
+    |radius - d| of the descent (nn_tile.hip, chain_lb).  Every internal node has a tree point
+    exactly ON its sphere (the median element, vp-tree.cc:48-52,77), and every centre is a tree
+    point: queries a few ulps away from the tree's own points put the answer's distance, the
+    distances to the spheres and the centre distances all at the same rounding-level scale."""
+    from icp_amd import capi, synth
+    n, cap = 120_000, 16
+    m = synth.cloud(n, seed=4242)
+    mu_m = capi.mean_host(m)
+    mc = capi.center_host(m, mu_m)
+    rng = np.random.default_rng(ulps)
+    k = rng.integers(-ulps, ulps + 1, size=mc.shape).astype(np.int32)
+    q = (mc.view(np.int32) + k).view(np.float32)  # neighbouring floats of the tree's coordinates
+    q = np.ascontiguousarray(q)
+    assert np.isfinite(q).all()
+    want = oracle.tree_closest(oracle.tree_build(cap, mc), q)
+    tree = capi.FlatTree(mc, cap)
+    zero = np.zeros(3, np.float32)
+    _same(_nn(capi, tree, q, zero), want)
+    _same(_nn(capi, tree, q, zero, {"ICP_HIP_NN_KERNEL": "deep"}), want)
+    tree.close()
