@@ -32,6 +32,7 @@
 // wave-cooperative scan of device_common.hh.
 
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "device_common.hh"
@@ -66,6 +67,9 @@ namespace icp_dev
             double sums[kCovSums + 4]; // this wave's running totals (fixed summation order)
         };
         static_assert(sizeof(WaveLds) <= 8192, "LDS budget: 4 waves x 8 KiB = 32 KiB per workgroup");
+        static_assert(offsetof(WaveLds, by) - offsetof(WaveLds, bx) == (kImage + 4) * sizeof(float) &&
+                          offsetof(WaveLds, bz) - offsetof(WaveLds, by) == (kImage + 4) * sizeof(float),
+                      "tile_scan addresses by and bz relative to bx");
 
         __device__ __forceinline__ void wave_lds_fence()
         {
@@ -80,6 +84,49 @@ namespace icp_dev
         {
             m2 = __builtin_amdgcn_fmed3f(m, m2, v);
             m = fminf(m, v);
+        }
+
+        // ---- fixed-order wave sums of doubles without LDS traffic (gfx950 permlane swaps) ----
+        // [a | b] : lanes 0..31 get a[l] + a[l+32], lanes 32..63 get b[l-32] + b[l]
+        __device__ __forceinline__ double swap_add_halves(double a, double b)
+        {
+            const uint64_t ua = (uint64_t)__double_as_longlong(a), ub = (uint64_t)__double_as_longlong(b);
+            const auto lo = __builtin_amdgcn_permlane32_swap((uint32_t)ua, (uint32_t)ub, false, false);
+            const auto hi = __builtin_amdgcn_permlane32_swap((uint32_t)(ua >> 32), (uint32_t)(ub >> 32),
+                                                             false, false);
+            const double x = __longlong_as_double((long long)(((uint64_t)hi[0] << 32) | lo[0]));
+            const double y = __longlong_as_double((long long)(((uint64_t)hi[1] << 32) | lo[1]));
+            return x + y;
+        }
+        // a, b hold two 32-lane halves each: rows of 16 lanes become a.row0+a.row1, b.row0+b.row1,
+        // a.row2+a.row3, b.row2+b.row3
+        __device__ __forceinline__ double swap_add_rows(double a, double b)
+        {
+            const uint64_t ua = (uint64_t)__double_as_longlong(a), ub = (uint64_t)__double_as_longlong(b);
+            const auto lo = __builtin_amdgcn_permlane16_swap((uint32_t)ua, (uint32_t)ub, false, false);
+            const auto hi = __builtin_amdgcn_permlane16_swap((uint32_t)(ua >> 32), (uint32_t)(ub >> 32),
+                                                             false, false);
+            const double x = __longlong_as_double((long long)(((uint64_t)hi[0] << 32) | lo[0]));
+            const double y = __longlong_as_double((long long)(((uint64_t)hi[1] << 32) | lo[1]));
+            return x + y;
+        }
+        template <int CTRL>
+        __device__ __forceinline__ double dpp_shr_zero(double v)
+        {
+            const uint64_t u = (uint64_t)__double_as_longlong(v);
+            // bound_ctrl: lanes without a source read 0 = +0.0
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, CTRL, 0xf, 0xf, true);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), CTRL, 0xf, 0xf, true);
+            return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+        }
+        // lane 15 of every 16-lane row ends with the sum of its row
+        __device__ __forceinline__ double row_sum_f64(double v)
+        {
+            v += dpp_shr_zero<0x111>(v); // row_shr:1
+            v += dpp_shr_zero<0x112>(v); // row_shr:2
+            v += dpp_shr_zero<0x114>(v); // row_shr:4
+            v += dpp_shr_zero<0x118>(v); // row_shr:8
+            return v;
         }
 
         // Tile scan of bucket [beg, beg+cnt) for the g lanes in `grp` (all of them wait on it).
@@ -136,32 +183,56 @@ namespace icp_dev
                 const float4 q = L.qb[slot];
                 const uint32_t n4 = (cw + 3u) >> 2;           // float4 groups in the window
                 const uint32_t steps = (n4 + P - 1u) / P;     // wave-uniform
-                uint32_t gi = idle ? (uint32_t)kGroups : part; // group of this lane at step 0
+                // byte offset of this lane's float4 group in bx/by/bz.  Lanes past the last whole
+                // part shadow part 0: nothing folds their results in.  Every group below kGroups
+                // is staged (+inf behind the bucket), group kGroups is the +inf pad; only a scan
+                // that can step past it (P * steps > kGroups + 1: long buckets in many parts)
+                // clamps its offsets.
+                const char* const img = reinterpret_cast<const char*>(L.bx);
+                const char* gp = img + (idle ? 0u : 16u * part); // this lane's group in bx
+                const uint32_t gstride = 16u * P;
                 const float m_before = m;
-                uint32_t kbest = 0;
-#pragma unroll 2
-                for (uint32_t k = 0; k < steps; ++k)
-                {
-                    const uint32_t gc = min(gi, (uint32_t)kGroups); // group 64 is all +inf
-                    const float4 X = *reinterpret_cast<const float4*>(L.bx + 4u * gc);
-                    const float4 Y = *reinterpret_cast<const float4*>(L.by + 4u * gc);
-                    const float4 Z = *reinterpret_cast<const float4*>(L.bz + 4u * gc);
+                const char* bp = img; // group of the smallest minimum so far
+                constexpr uint32_t kBy = (kImage + 4) * sizeof(float), kBz = 2u * kBy;
+                auto step = [&](const char* at) {
+                    const float4 X = *reinterpret_cast<const float4*>(at);
+                    const float4 Y = *reinterpret_cast<const float4*>(at + kBy);
+                    const float4 Z = *reinterpret_cast<const float4*>(at + kBz);
                     const float d0 = sq_dist(q.x, q.y, q.z, X.x, Y.x, Z.x);
                     const float d1 = sq_dist(q.x, q.y, q.z, X.y, Y.y, Z.y);
                     const float d2 = sq_dist(q.x, q.y, q.z, X.z, Y.z, Z.z);
                     const float d3 = sq_dist(q.x, q.y, q.z, X.w, Y.w, Z.w);
                     const float gm = fminf(fminf(fminf(d0, d1), d2), d3);
-                    kbest = (gm < m) ? k : kbest;
-                    track2(gm, m, m2);
-                    gi += P;
+                    bp = (gm < m) ? at : bp;
+                    m2 = __builtin_amdgcn_fmed3f(m, m2, gm);
+                    // distances are >= 0 (or +inf): they order like their bit patterns
+                    m = __uint_as_float(min(__float_as_uint(m), __float_as_uint(gm)));
+                };
+                if (P * steps <= (uint32_t)kGroups + 1u)
+                {
+#pragma unroll 2
+                    for (uint32_t k = 0; k < steps; ++k)
+                    {
+                        step(gp);
+                        gp += gstride;
+                    }
+                }
+                else
+                {
+                    const char* const pad = img + 16u * (uint32_t)kGroups;
+#pragma nounroll
+                    for (uint32_t k = 0; k < steps; ++k)
+                    {
+                        step(gp < pad ? gp : pad);
+                        gp += gstride;
+                    }
                 }
                 if (m < m_before)
                 {
                     // the winning group again: slot of m and the runner-up inside the group
-                    const uint32_t gw = part + P * kbest;
-                    const float4 X = *reinterpret_cast<const float4*>(L.bx + 4u * gw);
-                    const float4 Y = *reinterpret_cast<const float4*>(L.by + 4u * gw);
-                    const float4 Z = *reinterpret_cast<const float4*>(L.bz + 4u * gw);
+                    const float4 X = *reinterpret_cast<const float4*>(bp);
+                    const float4 Y = *reinterpret_cast<const float4*>(bp + kBy);
+                    const float4 Z = *reinterpret_cast<const float4*>(bp + kBz);
                     const float d0 = sq_dist(q.x, q.y, q.z, X.x, Y.x, Z.x);
                     const float d1 = sq_dist(q.x, q.y, q.z, X.y, Y.y, Z.y);
                     const float d2 = sq_dist(q.x, q.y, q.z, X.z, Y.z, Z.z);
@@ -172,7 +243,7 @@ namespace icp_dev
                     track2(d2, a, b2);
                     track2(d3, a, b2);
                     const uint32_t c = (d0 == m) ? 0u : (d1 == m) ? 1u : (d2 == m) ? 2u : 3u;
-                    idx = w0 + 4u * gw + c;
+                    idx = w0 + ((uint32_t)(bp - img) >> 2) + c;
                     m2 = fminf(m2, b2);
                 }
                 wave_lds_fence(); // the next window overwrites the image
@@ -653,7 +724,9 @@ namespace icp_dev
                     }
                 }
                 // fp32 products as find_covariance forms them (point-3d.cc:220-231), summed in
-                // fp64: lanes -> wave (fixed shuffle tree) -> this wave's running totals in LDS
+                // fp64 in a fixed order: twelve per-lane values -> (permlane32 swap) six registers
+                // of two 32-lane halves -> (permlane16 swap) three registers of four 16-lane rows
+                // -> row sums by DPP -> this wave's running totals in LDS.
                 {
                     double v[kCovSums];
                     v[0] = (double)__fmul_rn(qx, ox);
@@ -668,12 +741,20 @@ namespace icp_dev
                     v[9] = (double)n_int;
                     v[10] = (double)n_pts;
                     v[11] = (double)ovf;
+                    double h[6], r[3];
 #pragma unroll
-                    for (int k = 0; k < kCovSums; ++k)
+                    for (int k = 0; k < 6; ++k)
+                        h[k] = swap_add_halves(v[2 * k], v[2 * k + 1]); // [v2k | v2k+1]
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) // rows: v4k, v4k+2, v4k+1, v4k+3
+                        r[k] = row_sum_f64(swap_add_rows(h[2 * k], h[2 * k + 1]));
+                    if ((lane & 15) == 15) // the last lane of a row holds the row's sum
                     {
-                        const double sk = wave_sum_f64(v[k]); // invalid lanes carry zeros
-                        if (lane == 0)
-                            L.sums[k] += sk;
+                        const int row = lane >> 4;
+                        const int k0 = ((row & 1) << 1) | (row >> 1);
+#pragma unroll
+                        for (int k = 0; k < 3; ++k)
+                            L.sums[4 * k + k0] += r[k];
                     }
                 }
             }
