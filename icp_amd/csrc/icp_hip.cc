@@ -159,7 +159,7 @@ struct icp_hip_ctx
     uint32_t chunk_batches = 1, n_chunks = 0, tile_grid_blocks = 8, spill_levels = 0;
     uint32_t batch_queries = 64; // queries per wave-batch of nn_tile_kernel (prepare_tile)
     bool tile_ready = false;
-    uint32_t tile_cut = 1; // ICP_HIP_TILE_CUT overrides (0 = run the node phase to the end)
+    uint32_t tile_cut = 4; // in 16ths; ICP_HIP_TILE_CUT overrides (0 = run the node phase to the end)
 
     icp_hip_allreduce_fn allreduce = nullptr;
     void* allreduce_user = nullptr;

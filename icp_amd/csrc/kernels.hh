@@ -79,7 +79,7 @@ namespace icp_dev
         uint32_t* queue;        // kQueueWords words, zeroed by the launch
         uint2* spill;           // [max(0, height - stack entries)][grid * 256] or null
         unsigned long long* stats; // 8 event counters of the diagnostic build, or null
-        uint32_t cut; // leave the node phase when waiting lanes >= cut x stepping lanes (0: never)
+        uint32_t cut; // leave the node phase when waiting lanes >= cut/16 x stepping lanes (0: never)
     };
     hipError_t launch_nn_tile(const NnLaunch& a, const TileLaunch& q, hipStream_t s);
     hipError_t nn_tile_blocks_per_cu(int* out);

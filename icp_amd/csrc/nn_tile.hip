@@ -458,10 +458,11 @@ namespace icp_dev
                         if (stepping == 0ull)
                             break;
                         // a few stragglers deep in far subtrees must not hold up the lanes that
-                        // already wait on a bucket: serve those first once they outnumber the
-                        // stepping lanes `cut` to one
+                        // already wait on a bucket: serve those first once they are cut/16 of
+                        // the stepping lanes (default 4/16: measured 5 % faster on a misaligned
+                        // 32M cloud than 16/16, flat below)
                         if (cut != 0u &&
-                            (uint32_t)__builtin_popcountll(stepping) * cut <=
+                            (uint32_t)__builtin_popcountll(stepping) * cut <= 16u *
                                 (uint32_t)__builtin_popcountll(__ballot(mode == tWaitLeaf)))
                             break;
                         if (STATS)
