@@ -19,12 +19,15 @@
 // device buffers) across calls, which is what a long-lived caller of icp_hip_icp gets.
 //
 //   icp_bench [--data DIR] [--npy] [--capacities 8,16,..] [--files 0,1,..|none] [--min-time SECONDS]
-//             [--reuse-context] [--phases] [--synthetic N[:ANGLE_DEG]] [--device cpu|gpu]
+//             [--reuse-context] [--phases] [--timers] [--synthetic N[:ANGLE_DEG]]
+//             [--device cpu|gpu]
 //
 //   --data DIR     the reference's data directory (default ../data, as the reference's paths are
 //                  relative to build/); with --npy: a directory of <name>.npy float32 (n,3) files
 //                  (tests/golden/data)
 //   --phases       additionally time the steps of one call separately (stderr, one line per case)
+//   --timers       fill the nn_kernel_ms column (HIP events around every NN pass; they cost about
+//                  20 us per iteration, so they are off when the call is what is timed)
 //   --synthetic    add the synthetic cloud of bench.py (N points, rigid motion of ANGLE degrees,
 //                  default 1) as one more file pair
 //   --device cpu   BM_CPU is the reference's own libcpu, which this repository does not contain:
@@ -213,6 +216,8 @@ namespace
         Cloud q, p; // reference, transformed
     };
 
+    bool g_timers = false; // --timers: collect nn_kernel_ms (costs ~20 us per iteration)
+
     struct OneCall
     {
         uint64_t iterations = 0;
@@ -227,6 +232,7 @@ namespace
         icp_hip_ctx* ctx = persistent;
         if (!ctx)
             check(icp_hip_create(&ctx, -1), nullptr, "icp_hip_create");
+        icp_hip_set_phase_timers(ctx, g_timers ? 1 : 0);
         float T[16];
         OneCall r;
         const int rc = icp_hip_icp(ctx, c.q.xyz.data(), c.q.n(), c.p.xyz.data(), c.p.n(), 200, 1e-5f,
@@ -322,6 +328,8 @@ int main(int argc, char* argv[])
                 reuse = true;
             else if (a == "--phases")
                 phases = true;
+            else if (a == "--timers")
+                g_timers = true;
             else if (a == "--synthetic")
             {
                 const std::string v = value();

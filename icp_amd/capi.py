@@ -25,6 +25,7 @@ EXPORTS = [
     "icp_hip_set_queries", "icp_hip_nn",
     "icp_hip_set_allreduce", "icp_hip_comm_unique_id", "icp_hip_comm_init_rank", "icp_hip_run",
     "icp_hip_get_points", "icp_hip_get_timing", "icp_hip_get_nn_trace", "icp_hip_icp",
+    "icp_hip_set_phase_timers",
 ]
 
 
@@ -109,6 +110,7 @@ def load() -> C.CDLL:
     L.icp_hip_get_points.argtypes = [vp, vp]
     L.icp_hip_icp.argtypes = [vp, vp, u64, vp, u64, u64, C.c_float, u32, vp, vp, C.POINTER(u64),
                               C.POINTER(C.c_float), PROGRESS_FN, vp]
+    L.icp_hip_set_phase_timers.argtypes = [vp, C.c_int]
     L.icp_hip_get_timing.argtypes = [vp, C.POINTER(TimingStruct)]
     L.icp_hip_get_nn_trace.argtypes = [vp, vp, u64, C.POINTER(u64)]
     _lib = L
@@ -225,12 +227,15 @@ class FlatTree:
 class Context:
     """One GPU, one shard of queries, one replica of the tree."""
 
-    def __init__(self, device_id: int = -1):
+    def __init__(self, device_id: int = -1, phase_timers: bool = True):
         self._L = load()
         self._h = C.c_void_p()
         _check(self._L.icp_hip_create(C.byref(self._h), int(device_id)))
         self._keep = []
         self.n_local = 0
+        # timing() / nn_trace() are part of this wrapper's interface (bench.py, tests); a C caller
+        # gets a context without the per-iteration events (icp_hip_set_phase_timers)
+        _check(self._L.icp_hip_set_phase_timers(self._h, 1 if phase_timers else 0), self._h)
 
     def close(self):
         if self._h:

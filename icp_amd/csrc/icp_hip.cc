@@ -168,6 +168,14 @@ struct icp_hip_ctx
 
     icp_hip_timing timing{};
     std::vector<float> nn_trace; // NN kernel ms of each iteration of the last icp_hip_run
+
+    // device-resident loop (loop.hip): state on the device, its pinned host copy, 4 events per
+    // enqueued iteration; ICP_HIP_LOOP=host|device overrides the choice
+    LoopState* loop_state = nullptr; // behind the 16 doubles of `sums` (one allocation)
+    LoopState* h_loop = nullptr;     // behind the 16 doubles of `h_sums`
+    std::vector<hipEvent_t> loop_events;
+    int loop_mode = 0; // 0 auto, 1 host-driven, 2 device-resident
+    bool phase_timers = false; // icp_hip_set_phase_timers
 };
 
 namespace
@@ -557,6 +565,155 @@ namespace
         c->has_tree = true;
         return prepare_tile(c);
     }
+
+    // One iteration of the device-resident loop, enqueued without waiting for anything:
+    // NN + covariance, its sums, the solve, apply + error, its sums, the loop condition.
+    int enqueue_iteration(icp_hip_ctx* c, hipEvent_t* ev)
+    {
+        const uint32_t n = (uint32_t)c->n_local;
+        const float zero[3] = {0.f, 0.f, 0.f};
+        NnLaunch a = make_nn(c, zero, true, false, false, true);
+        a.loop = c->loop_state;
+        a.grid = c->tile_grid_blocks;
+        TileLaunch q{c->chunk_batches, c->batch_queries, c->chunk_sums.p, c->queue.p,
+                     c->spill.p, nullptr, c->tile_cut};
+        const bool timed = c->phase_timers; // an event costs ~5 us of stream time
+        if (timed)
+            HIP_TRY(c, hipEventRecord(ev[0], c->stream));
+        HIP_TRY(c, launch_nn_tile(a, q, c->stream));
+        if (timed)
+            HIP_TRY(c, hipEventRecord(ev[1], c->stream));
+        uint32_t g1 = (c->n_chunks + 63) / 64;
+        g1 = g1 > 1024 ? 1024 : g1;
+        HIP_TRY(c, launch_reduce_rows(c->chunk_sums.p, c->n_chunks, kCovSums, g1, c->partials.p,
+                                      c->stream));
+        HIP_TRY(c, launch_reduce_partials(c->partials.p, g1, kCovSums, c->sums.p, c->stream));
+        auto allreduce = [&](int count) -> int {
+            if (!c->comm)
+                return ICP_HIP_OK;
+            const int rc = g_rccl.AllReduce(c->sums.p, c->sums.p, (size_t)count, Rccl::kDouble,
+                                            Rccl::kSum, c->comm, c->stream);
+            if (rc != 0)
+                return fail(c, ICP_HIP_ERR_COMM,
+                            std::string("ncclAllReduce: ") +
+                                (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"));
+            return ICP_HIP_OK;
+        };
+        int rc = allreduce(kCovSums);
+        if (rc != ICP_HIP_OK)
+            return rc;
+        HIP_TRY(c, launch_loop_solve(c->loop_state, c->sums.p, c->stream));
+        const uint32_t g_st = stream_grid(n);
+        Mat34 unused{};
+        if (timed)
+            HIP_TRY(c, hipEventRecord(ev[2], c->stream));
+        HIP_TRY(c, launch_apply_error(c->px.p, c->py.p, c->pz.p, c->yx.p, c->yy.p, c->yz.p, unused,
+                                      zero, n, g_st, c->partials.p, c->loop_state, c->stream));
+        if (timed)
+            HIP_TRY(c, hipEventRecord(ev[3], c->stream));
+        HIP_TRY(c, launch_reduce_partials(c->partials.p, g_st, kApplySums, c->sums.p, c->stream));
+        if ((rc = allreduce(kApplySums)) != ICP_HIP_OK)
+            return rc;
+        HIP_TRY(c, launch_loop_finish(c->loop_state, c->sums.p, c->stream));
+        return ICP_HIP_OK;
+    }
+
+    // libcpu::icp's loop (icp.cc:110-125) with the host out of the iteration: iterations are
+    // enqueued in blocks of 1, 2, 4, 8, 8, .. and the state is read back once per block; what was
+    // enqueued past the end of the loop finds `done` set and does nothing.  With an RCCL
+    // communicator the block is one iteration, so that every rank issues the same collectives
+    // whichever loop it runs.
+    int run_device_loop(icp_hip_ctx* c, const float mu_m[3], uint64_t max_iters, float threshold,
+                        float T_out[16], uint64_t* iters_done, float* final_error,
+                        icp_hip_progress_fn progress, void* user)
+    {
+        const auto t_begin = std::chrono::steady_clock::now();
+        const uint32_t n = (uint32_t)c->n_local;
+        const uint32_t g_st = stream_grid(n);
+        c->nn_trace.clear();
+        const uint32_t cap_iters = max_iters > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)max_iters;
+        uint32_t it_done = 0;
+        float error = std::numeric_limits<float>::infinity();
+        float T[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        if (cap_iters > 0 && error > threshold)
+        {
+            // first mean(p) (icp.cc:114); later iterations get it from the apply pass
+            HIP_TRY(c, launch_sum_points(c->px.p, c->py.p, c->pz.p, n, g_st, c->partials.p,
+                                         c->stream));
+            HIP_TRY(c, launch_reduce_partials(c->partials.p, g_st, kApplySums, c->sums.p,
+                                              c->stream));
+            if (c->comm)
+            {
+                const int rc = g_rccl.AllReduce(c->sums.p, c->sums.p, (size_t)kApplySums,
+                                                Rccl::kDouble, Rccl::kSum, c->comm, c->stream);
+                if (rc != 0)
+                    return fail(c, ICP_HIP_ERR_COMM, "ncclAllReduce failed");
+            }
+            HIP_TRY(c, launch_loop_init(c->loop_state, c->sums.p, mu_m, threshold, cap_iters,
+                                        (double)c->n_total, c->stream));
+            uint32_t block = 1;
+            for (;;)
+            {
+                uint32_t B = c->comm ? 1u : block;
+                if (B > cap_iters - it_done)
+                    B = cap_iters - it_done;
+                while (c->phase_timers && c->loop_events.size() < (size_t)4 * B)
+                {
+                    hipEvent_t ev = nullptr;
+                    HIP_TRY(c, hipEventCreate(&ev));
+                    c->loop_events.push_back(ev);
+                }
+                for (uint32_t s = 0; s < B; ++s)
+                {
+                    const int rc = enqueue_iteration(
+                        c, c->phase_timers ? c->loop_events.data() + 4 * s : nullptr);
+                    if (rc != ICP_HIP_OK)
+                        return rc;
+                }
+                HIP_TRY(c, hipMemcpyAsync(c->h_loop, c->loop_state, sizeof(LoopState),
+                                          hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                const LoopState& st = *c->h_loop;
+                for (uint32_t i = it_done; i < st.it; ++i)
+                {
+                    float nn_ms = 0.f, ap_ms = 0.f;
+                    if (c->phase_timers)
+                    {
+                        hipEvent_t* ev = c->loop_events.data() + 4 * (i - it_done);
+                        (void)hipEventElapsedTime(&nn_ms, ev[0], ev[1]);
+                        (void)hipEventElapsedTime(&ap_ms, ev[2], ev[3]);
+                    }
+                    c->timing.nn_ms += nn_ms;
+                    c->timing.apply_ms += ap_ms;
+                    c->timing.nn_launches += 1;
+                    c->timing.queries += (double)c->n_total;
+                    if (c->phase_timers && c->nn_trace.size() < 4096)
+                        c->nn_trace.push_back(nn_ms);
+                    if (progress)
+                        progress(i + 1, max_iters, st.errors[i % (uint32_t)kLoopBlockMax], user);
+                }
+                it_done = st.it;
+                if (st.done || it_done >= cap_iters)
+                    break;
+                block = block * 2 > (uint32_t)kLoopBlockMax ? (uint32_t)kLoopBlockMax : block * 2;
+            }
+            const LoopState& st = *c->h_loop;
+            std::memcpy(T, st.T, sizeof T);
+            error = st.error;
+            c->timing.nodes_visited += st.work[0];
+            c->timing.points_scanned += st.work[1];
+            c->timing.stack_spills += st.work[2];
+        }
+        std::memcpy(T_out, T, sizeof T);
+        if (iters_done)
+            *iters_done = it_done;
+        if (final_error)
+            *final_error = error;
+        c->timing.host_ms +=
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin)
+                .count();
+        return ICP_HIP_OK;
+    }
 } // namespace
 
 extern "C"
@@ -707,11 +864,21 @@ extern "C"
             return bail(e, "hipEventCreate");
         if ((e = hipEventCreate(&c->ev1)) != hipSuccess)
             return bail(e, "hipEventCreate");
-        if ((e = hipHostMalloc((void**)&c->h_sums, 16 * sizeof(double), hipHostMallocDefault)) !=
-            hipSuccess)
+        // 16 doubles of sums + the device-resident loop's state, on the device and pinned
+        constexpr size_t kStateDoubles = (sizeof(LoopState) + sizeof(double) - 1) / sizeof(double);
+        if ((e = hipHostMalloc((void**)&c->h_sums, (16 + kStateDoubles) * sizeof(double),
+                               hipHostMallocDefault)) != hipSuccess)
             return bail(e, "hipHostMalloc");
-        if ((e = c->sums.alloc(16)) != hipSuccess)
+        c->h_loop = reinterpret_cast<LoopState*>(c->h_sums + 16);
+        if ((e = c->sums.alloc(16 + kStateDoubles)) != hipSuccess)
             return bail(e, "hipMalloc(sums)");
+        c->loop_state = reinterpret_cast<LoopState*>(c->sums.p + 16);
+        {
+            const char* lm = std::getenv("ICP_HIP_LOOP");
+            c->loop_mode = !lm ? 0 : std::strcmp(lm, "host") == 0 ? 1
+                                 : std::strcmp(lm, "device") == 0 ? 2
+                                                                  : 0;
+        }
         {
             int per_cu = 0, cus = 0;
             if ((e = nn_tile_blocks_per_cu(&per_cu)) != hipSuccess)
@@ -771,6 +938,8 @@ extern "C"
         c->sums.release();
         if (c->h_sums)
             (void)hipHostFree(c->h_sums);
+        for (hipEvent_t ev : c->loop_events)
+            (void)hipEventDestroy(ev);
         if (c->ev0)
             (void)hipEventDestroy(c->ev0);
         if (c->ev1)
@@ -1139,6 +1308,14 @@ extern "C"
         if (!c->has_tree || !c->has_queries)
             return fail(c, ICP_HIP_ERR_ARG, "icp_hip_run: set_tree and set_queries must come first");
         DeviceGuard g(c->device);
+        // The loop stays on the device unless something needs the host between the kernels: the
+        // all-reduce callback, the diagnostic counters, the level-stack kernel.  Both loops give
+        // the same bits (tests/test_gpu_icp_parity.py).
+        const bool can_device = c->tile_ready && !c->force_deep && !c->stats.p && !c->allreduce &&
+                                c->n_local > 0;
+        if (c->loop_mode != 1 && can_device)
+            return run_device_loop(c, mu_m, max_iters, threshold, T_out, iters_done, final_error,
+                                   progress, user);
         const auto t_begin = std::chrono::steady_clock::now();
         const uint32_t n = (uint32_t)c->n_local;
         const uint32_t g_st = stream_grid(n);
@@ -1197,7 +1374,7 @@ extern "C"
             std::memcpy(M.m, Tn, sizeof M.m);
             HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
             HIP_TRY(c, launch_apply_error(c->px.p, c->py.p, c->pz.p, c->yx.p, c->yy.p, c->yz.p, M,
-                                          mu_m, n, g_st, c->partials.p, c->stream));
+                                          mu_m, n, g_st, c->partials.p, nullptr, c->stream));
             HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
             HIP_TRY(c, launch_reduce_partials(c->partials.p, g_st, kApplySums, c->sums.p,
                                               c->stream));
@@ -1288,6 +1465,14 @@ extern "C"
         if (ms_out)
             for (uint64_t i = 0; i < capacity && i < c->nn_trace.size(); ++i)
                 ms_out[i] = c->nn_trace[i];
+        return ICP_HIP_OK;
+    }
+
+    int icp_hip_set_phase_timers(icp_hip_ctx* c, int enabled)
+    {
+        if (!c)
+            return fail(nullptr, ICP_HIP_ERR_ARG, "icp_hip_set_phase_timers: ctx is NULL");
+        c->phase_timers = enabled != 0;
         return ICP_HIP_OK;
     }
 

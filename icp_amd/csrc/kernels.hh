@@ -45,6 +45,28 @@ namespace icp_dev
     constexpr uint32_t kSlotSlack = 256; // a staged bucket window may read this far past a bucket
     constexpr uint32_t kStreamMaxBlocks = 256 * 8;
 
+    // State of a registration loop that stays on the device (loop.hip): the host enqueues
+    // iterations ahead and reads this back once per block; every kernel of an iteration does
+    // nothing once `done` is set, so iterations enqueued past the end of the loop
+    // (libcpu/libcpu/icp.cc:110: i < iterations && error > threshold) change nothing.
+    constexpr int kLoopBlockMax = 8; // iterations enqueued between two readbacks
+    struct LoopState
+    {
+        float T[16];     // accumulated transform (icp.cc:121)
+        float Tn[12];    // rows 0..2 of this iteration's transform, read by apply_error_kernel
+        float mu_p[3];   // centroid of the moved cloud, read by the NN kernel (icp.cc:114)
+        float mu_m[3];
+        float error;     // icp.cc:123
+        float threshold;
+        uint32_t it;     // iterations completed
+        uint32_t max_iters;
+        uint32_t done;
+        uint32_t pad_;
+        double n_total;
+        double work[3];  // reference-traversal counters summed over the iterations (sums 9..11)
+        float errors[kLoopBlockMax]; // error after iteration i at [i % kLoopBlockMax]
+    };
+
     struct NnLaunch
     {
         DevTree tree;
@@ -59,6 +81,7 @@ namespace icp_dev
         const uint32_t* perm; // may be null: row_out/dist_out are written at perm[i] (input order)
         double* partials;    // [grid][kCovSums] or null
         uint32_t grid;
+        const LoopState* loop; // device-resident loop: mu comes from loop->mu_p, no-op once done
     };
 
     int nn_max_depth_supported();
@@ -87,9 +110,16 @@ namespace icp_dev
     // out[b][k] = sum of rows [b*rows_per_block, ...) of rows[n_rows][K], fixed order; K <= 16
     hipError_t launch_reduce_rows(const double* rows, uint32_t n_rows, int K, uint32_t grid,
                                   double* out, hipStream_t s);
+    // `loop` null: T and mu_m are the arguments; else they are loop->Tn / loop->mu_m
     hipError_t launch_apply_error(float* px, float* py, float* pz, const float* yx, const float* yy,
                                   const float* yz, const Mat34& T, const float mu_m[3], uint32_t n,
-                                  uint32_t grid, double* partials, hipStream_t s);
+                                  uint32_t grid, double* partials, const LoopState* loop,
+                                  hipStream_t s);
+    // loop.hip: single-thread steps of the device-resident loop
+    hipError_t launch_loop_init(LoopState* st, const double* sums, const float mu_m[3],
+                                float threshold, uint32_t max_iters, double n_total, hipStream_t s);
+    hipError_t launch_loop_solve(LoopState* st, const double* sums, hipStream_t s);
+    hipError_t launch_loop_finish(LoopState* st, const double* sums, hipStream_t s);
     hipError_t launch_sum_points(const float* px, const float* py, const float* pz, uint32_t n,
                                  uint32_t grid, double* partials, hipStream_t s);
     hipError_t launch_reduce_partials(const double* partials, uint32_t nblocks, int K, double* out,

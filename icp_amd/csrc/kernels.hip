@@ -251,9 +251,23 @@ namespace icp_dev
         apply_error_kernel(float* __restrict__ px, float* __restrict__ py, float* __restrict__ pz,
                            const float* __restrict__ yx, const float* __restrict__ yy,
                            const float* __restrict__ yz, Mat34 T, float mmx, float mmy, float mmz,
-                           uint32_t n, double* __restrict__ partials)
+                           uint32_t n, double* __restrict__ partials,
+                           const LoopState* __restrict__ loop)
     {
         __shared__ double s_red[kWavesPerBlock * kApplySums];
+        if (loop)
+        {
+            // device-resident loop: this iteration's transform was written by loop_solve_kernel;
+            // an iteration enqueued past the end of the loop moves nothing
+            if (loop->done)
+                return;
+#pragma unroll
+            for (int k = 0; k < 12; ++k)
+                T.m[k] = loop->Tn[k];
+            mmx = loop->mu_m[0];
+            mmy = loop->mu_m[1];
+            mmz = loop->mu_m[2];
+        }
         double acc[kApplySums] = {0.0, 0.0, 0.0, 0.0};
         for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
         {
@@ -454,10 +468,11 @@ namespace icp_dev
 
     hipError_t launch_apply_error(float* px, float* py, float* pz, const float* yx, const float* yy,
                                   const float* yz, const Mat34& T, const float mu_m[3], uint32_t n,
-                                  uint32_t grid, double* partials, hipStream_t s)
+                                  uint32_t grid, double* partials, const LoopState* loop,
+                                  hipStream_t s)
     {
         hipLaunchKernelGGL(apply_error_kernel, dim3(grid), dim3(kBlock), 0, s, px, py, pz, yx, yy,
-                           yz, T, mu_m[0], mu_m[1], mu_m[2], n, partials);
+                           yz, T, mu_m[0], mu_m[1], mu_m[2], n, partials, loop);
         return hipGetLastError();
     }
 

@@ -352,9 +352,20 @@ namespace icp_dev
                            uint32_t* __restrict__ queue, uint2* __restrict__ spill,
                            uint32_t n_batches, uint32_t chunk_batches, uint32_t n_chunks,
                            uint32_t cut, uint32_t batch_queries,
-                           unsigned long long* __restrict__ stats)
+                           unsigned long long* __restrict__ stats,
+                           const LoopState* __restrict__ loop)
         {
             __shared__ WaveLds s_w[kWavesPerBlock];
+            if (loop)
+            {
+                // device-resident loop (loop.hip): the centroid comes from the previous
+                // iteration's sums; an iteration enqueued past the end of the loop does nothing
+                if (loop->done)
+                    return;
+                mux = loop->mu_p[0];
+                muy = loop->mu_p[1];
+                muz = loop->mu_p[2];
+            }
             // wave-level event counts of the diagnostic build (ICP_HIP_TILE_STATS=1)
             uint32_t st_node = 0, st_tile = 0, st_tile_g = 0, st_tile_len = 0, st_coop = 0,
                      st_exact = 0, st_leafph = 0, st_batch = 0, st_node_lanes = 0;
@@ -800,12 +811,12 @@ namespace icp_dev
             hipLaunchKernelGGL(nn_tile_kernel<true>, dim3(a.grid), dim3(kBlock), 0, s, a.tree, a.px,
                                a.py, a.pz, a.mu[0], a.mu[1], a.mu[2], a.n, a.yx, a.yy, a.yz,
                                a.row_out, a.dist_out, a.perm, q.chunk_sums, q.queue, q.spill,
-                               n_batches, q.chunk_batches, n_chunks, q.cut, bq, q.stats);
+                               n_batches, q.chunk_batches, n_chunks, q.cut, bq, q.stats, a.loop);
         else
             hipLaunchKernelGGL(nn_tile_kernel<false>, dim3(a.grid), dim3(kBlock), 0, s, a.tree, a.px,
                                a.py, a.pz, a.mu[0], a.mu[1], a.mu[2], a.n, a.yx, a.yy, a.yz,
                                a.row_out, a.dist_out, a.perm, q.chunk_sums, q.queue, q.spill,
-                               n_batches, q.chunk_batches, n_chunks, q.cut, bq, nullptr);
+                               n_batches, q.chunk_batches, n_chunks, q.cut, bq, nullptr, a.loop);
         return hipGetLastError();
     }
 } // namespace icp_dev

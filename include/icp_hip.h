@@ -118,7 +118,8 @@ void icp_hip_free_points(float* xyz);
  * Replaces libgpu::find_rotation (libgpu/libgpu/svd.cc:7-28, Eigen JacobiSVD) and the
  * transpose/dot/subtract/to_transformation chain of libgpu/libgpu/icp.cu:35-62; semantics of
  * libcpu find_alignment + to_transformation (libcpu/libcpu/icp.cc:11-60).  icp_hip_run calls it
- * once per iteration. */
+ * once per iteration when it drives the loop from the host; the device-resident loop runs the
+ * same source (icp_amd/csrc/align3.hh) in a one-thread kernel and gives the same bits. */
 void icp_hip_alignment_host(const float H[9], const float mu_p[3], const float mu_m[3],
                             float T_out[16]);
 
@@ -191,8 +192,15 @@ int icp_hip_comm_init_rank(icp_hip_ctx* ctx, int n_ranks, int rank, const void* 
  * semantics of libcpu::icp (libcpu/libcpu/icp.cc:110-125):
  *   for (i = 0; i < max_iters && error > threshold; ++i) { ... }      error starts at +inf
  * mu_m is mean(m) as icp_hip_mean_host computes it.  progress (may be NULL) is called once per
- * iteration after the error is known (the reference prints "Starting iter" / "Error:" to
- * stderr there, icp.cc:112-113,124).  T_out is the accumulated 4x4 (icp.cc:121). */
+ * iteration, in order, with the iteration's error (the reference prints "Starting iter" /
+ * "Error:" to stderr there, icp.cc:112-113,124).  T_out is the accumulated 4x4 (icp.cc:121).
+ * Where libgpu copies nine floats to the host and back for the SVD in every iteration
+ * (icp.cu:57) and one float for the error (:157), the iteration here has no host step: solve,
+ * error and loop condition run in one-thread kernels, iterations are enqueued in blocks of
+ * 1, 2, 4, 8, 8, .. and the state is read back once per block (the calls to progress for a block
+ * follow its read-back); what was enqueued past the end of the loop does nothing.  With an
+ * all-reduce callback (icp_hip_set_allreduce) the host drives every iteration instead; both
+ * loops give the same bits (ICP_HIP_LOOP=host|device at icp_hip_create forces one). */
 typedef void (*icp_hip_progress_fn)(uint64_t iteration /*1-based*/, uint64_t max_iters,
                                     float error, void* user);
 int icp_hip_run(icp_hip_ctx* ctx, const float mu_m[3], uint64_t max_iters, float threshold,
@@ -219,7 +227,12 @@ int icp_hip_icp(icp_hip_ctx* ctx, const float* m_xyz, uint64_t n_m, const float*
                 icp_hip_progress_fn progress, void* user);
 
 /* Phase timers accumulated since the last icp_hip_set_queries (HIP events on the context's
- * stream; the reference has only gettimeofday around icp(), main.cc:29-40). */
+ * stream; the reference has only gettimeofday around icp(), main.cc:29-40).  The loop of
+ * icp_hip_run stays on the device between read-backs and an event costs about 5 us of stream
+ * time, four per iteration: nn_ms, apply_ms and the NN trace are only collected after
+ * icp_hip_set_phase_timers(ctx, 1) (off in a new context; bench.py and the tests turn them on).
+ * The launch count and the work counters are always kept; icp_hip_nn always times its pass. */
+int icp_hip_set_phase_timers(icp_hip_ctx* ctx, int enabled);
 typedef struct icp_hip_timing {
     uint64_t nn_launches;
     double nn_ms;      /* NN + covariance kernel                       */

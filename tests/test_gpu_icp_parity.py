@@ -138,3 +138,59 @@ def test_one_call_entry_point_and_context_reuse(clouds):
         assert e.value.status == 2  # capacity <= 2: undefined behaviour in the reference
         T, new_p, iters, err = ctx.icp(clouds["cow_ref"], clouds["cow_tr2"], 200, 1e-5, 32)
         assert (bits(T) == bits(ref["cow"][0])).all()
+
+
+def _run_loop(monkeypatch, mode, m, p, iters, thr, cap):
+    """icp_hip_run with the loop forced onto the host or onto the device (read at create)."""
+    import icp_amd
+    from icp_amd import capi
+    monkeypatch.setenv("ICP_HIP_LOOP", mode)
+    seen = []
+    mu_m = capi.mean_host(m)
+    with capi.Context() as ctx:
+        ctx.build_tree(capi.center_host(m, mu_m), cap)
+        ctx.set_queries(p)
+        T, it, err = ctx.run(mu_m, iters, thr, progress=lambda i, mx, e: seen.append((i, mx, e)))
+        new_p = ctx.get_points()
+        tm = ctx.timing()
+        trace = ctx.nn_trace()
+    return T, it, err, new_p, seen, tm, trace
+
+
+@pytest.mark.parametrize("name,tr,cap,iters,thr", [
+    ("horse", "horse_tr1", 32, 200, 1e-5), ("horse", "horse_tr2", 256, 200, 1e-5),
+    ("cow", "cow_tr1", 256, 200, 1e-5), ("cow", "cow_tr2", 8, 200, 1e-5),
+    ("line", "line_translated_2_3_4", 8, 200, 1e-5),
+    # the loop condition at every position of the enqueue blocks (1, 2, 4, 8, 8, ..)
+    ("cow", "cow_tr2", 256, 0, 0.0), ("cow", "cow_tr2", 256, 1, 0.0), ("cow", "cow_tr2", 256, 2, 0.0),
+    ("cow", "cow_tr2", 256, 3, 0.0), ("cow", "cow_tr2", 256, 4, 0.0), ("cow", "cow_tr2", 256, 7, 0.0),
+    ("cow", "cow_tr2", 256, 8, 0.0), ("cow", "cow_tr2", 256, 16, 0.0), ("cow", "cow_tr2", 256, 30, 0.0),
+    ("cow", "cow_tr2", 256, 200, float("inf")),  # error > threshold never holds: no iteration
+])
+def test_device_resident_loop_equals_host_loop(clouds, monkeypatch, name, tr, cap, iters, thr):
+    """The loop that stays on the GPU (loop.hip: solve, error and loop condition in one-thread
+    kernels, iterations enqueued ahead) gives the bits of the host-driven loop: transform, moved
+    cloud, iteration count, every error handed to the progress callback, the work counters."""
+    m, p = clouds[f"{name}_ref"], clouds[tr]
+    host = _run_loop(monkeypatch, "host", m, p, iters, thr, cap)
+    dev = _run_loop(monkeypatch, "device", m, p, iters, thr, cap)
+    assert host[1] == dev[1] and (iters == 0 or thr != 0.0 or dev[1] == iters)
+    assert (bits(host[0]) == bits(dev[0])).all()
+    assert bits(np.float32(host[2])) == bits(np.float32(dev[2]))
+    assert (bits(host[3]) == bits(dev[3])).all()
+    assert host[4] == dev[4] and len(dev[4]) == dev[1]
+    for k in ("nn_launches", "queries", "nodes_visited", "points_scanned", "stack_spills"):
+        assert host[5][k] == dev[5][k], k
+    assert len(dev[6]) == dev[1] and (dev[1] == 0 or dev[6].min() > 0)
+
+
+def test_device_resident_loop_solve_is_the_host_solve(clouds, monkeypatch):
+    """1M points, 12 iterations: any difference between the device and the host instance of
+    align3.hh would show in the accumulated transform."""
+    from icp_amd import synth
+    m = synth.cloud(1_000_000, seed=99)
+    p = synth.apply_fp32(m, synth.ground_truth(1.0))
+    host = _run_loop(monkeypatch, "host", m, p, 12, 0.0, 256)
+    dev = _run_loop(monkeypatch, "device", m, p, 12, 0.0, 256)
+    assert (bits(host[0]) == bits(dev[0])).all() and host[4] == dev[4]
+    assert (bits(host[3]) == bits(dev[3])).all()
