@@ -310,6 +310,8 @@ namespace
         const uint32_t k = nn_tile_stack_entries();
         c->spill_levels = c->height > k ? c->height - k : 0;
         HIP_TRY(c, c->queue.alloc(kQueueWords));
+        // zero once: every launch of nn_tile_kernel leaves the queue zeroed behind it
+        HIP_TRY(c, hipMemsetAsync(c->queue.p, 0, kQueueWords * sizeof(uint32_t), c->stream));
         {
             const char* env = std::getenv("ICP_HIP_TILE_STATS");
             if (env && env[0] == '1')
@@ -587,7 +589,9 @@ namespace
         g1 = g1 > 1024 ? 1024 : g1;
         HIP_TRY(c, launch_reduce_rows(c->chunk_sums.p, c->n_chunks, kCovSums, g1, c->partials.p,
                                       c->stream));
-        HIP_TRY(c, launch_reduce_partials(c->partials.p, g1, kCovSums, c->sums.p, c->stream));
+        // without a collective in between, the solve rides on the launch that makes its sums
+        HIP_TRY(c, launch_reduce_partials(c->partials.p, g1, kCovSums, c->sums.p, c->stream,
+                                          c->loop_state, c->comm ? kTailNone : kTailSolve));
         auto allreduce = [&](int count) -> int {
             if (!c->comm)
                 return ICP_HIP_OK;
@@ -602,7 +606,8 @@ namespace
         int rc = allreduce(kCovSums);
         if (rc != ICP_HIP_OK)
             return rc;
-        HIP_TRY(c, launch_loop_solve(c->loop_state, c->sums.p, c->stream));
+        if (c->comm)
+            HIP_TRY(c, launch_loop_solve(c->loop_state, c->sums.p, c->stream));
         const uint32_t g_st = stream_grid(n);
         Mat34 unused{};
         if (timed)
@@ -611,10 +616,12 @@ namespace
                                       zero, n, g_st, c->partials.p, c->loop_state, c->stream));
         if (timed)
             HIP_TRY(c, hipEventRecord(ev[3], c->stream));
-        HIP_TRY(c, launch_reduce_partials(c->partials.p, g_st, kApplySums, c->sums.p, c->stream));
+        HIP_TRY(c, launch_reduce_partials(c->partials.p, g_st, kApplySums, c->sums.p, c->stream,
+                                          c->loop_state, c->comm ? kTailNone : kTailFinish));
         if ((rc = allreduce(kApplySums)) != ICP_HIP_OK)
             return rc;
-        HIP_TRY(c, launch_loop_finish(c->loop_state, c->sums.p, c->stream));
+        if (c->comm)
+            HIP_TRY(c, launch_loop_finish(c->loop_state, c->sums.p, c->stream));
         return ICP_HIP_OK;
     }
 

@@ -90,7 +90,8 @@ namespace icp_dev
 
     hipError_t launch_nn(const NnLaunch& a, hipStream_t s);
     // nn_tile.hip: the production kernel (a.partials is not used: sums go to q.chunk_sums)
-    constexpr uint32_t kQueueWords = 256; // 8 queue heads, one per 128-byte line
+    constexpr uint32_t kQueueWords = 288; // 8 queue heads, one per 128-byte line, + the count of
+                                          // finished workgroups (word 256)
     struct TileLaunch
     {
         uint32_t chunk_batches; // batches per chunk (1..8)
@@ -99,7 +100,8 @@ namespace icp_dev
                                 // into narrower batches so that every SIMD gets waves, and the
                                 // idle lanes join the bucket scans as extra parts
         double* chunk_sums;     // [n_chunks][kCovSums] or null
-        uint32_t* queue;        // kQueueWords words, zeroed by the launch
+        uint32_t* queue;        // kQueueWords words, zero at launch; the last workgroup to finish
+                                // leaves them zero for the next launch
         uint2* spill;           // [max(0, height - stack entries)][grid * 256] or null
         unsigned long long* stats; // 8 event counters of the diagnostic build, or null
         uint32_t cut; // leave the node phase when waiting lanes >= cut/16 x stepping lanes (0: never)
@@ -122,8 +124,17 @@ namespace icp_dev
     hipError_t launch_loop_finish(LoopState* st, const double* sums, hipStream_t s);
     hipError_t launch_sum_points(const float* px, const float* py, const float* pz, uint32_t n,
                                  uint32_t grid, double* partials, hipStream_t s);
+    // `loop` + `tail`: the device-resident loop's scalar step on these sums, run by the same
+    // launch (and the launch does nothing once loop->done)
+    enum : int
+    {
+        kTailNone = 0,
+        kTailSolve = 1,
+        kTailFinish = 2
+    };
     hipError_t launch_reduce_partials(const double* partials, uint32_t nblocks, int K, double* out,
-                                      hipStream_t s);
+                                      hipStream_t s, LoopState* loop = nullptr,
+                                      int tail = kTailNone);
     hipError_t launch_aos_to_soa(const float* aos, uint32_t n, float* x, float* y, float* z,
                                  hipStream_t s);
     hipError_t launch_soa_to_aos(const float* x, const float* y, const float* z, uint32_t n,

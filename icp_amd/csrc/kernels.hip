@@ -23,6 +23,7 @@
 
 #include "device_common.hh"
 #include "kernels.hh"
+#include "loop_steps.hh"
 
 namespace icp_dev
 {
@@ -315,8 +316,10 @@ namespace icp_dev
     // out[k] = sum over blocks of partials[b*K + k], in a fixed order (bitwise reproducible).
     __global__ void __launch_bounds__(kBlock)
         reduce_partials_kernel(const double* __restrict__ partials, uint32_t nblocks, int K,
-                               double* __restrict__ out)
+                               double* out, LoopState* loop, int tail)
     {
+        if (loop && loop->done)
+            return; // an iteration enqueued past the end of the device-resident loop
         __shared__ double s[kBlock];
         for (int k = 0; k < K; ++k)
         {
@@ -334,6 +337,15 @@ namespace icp_dev
             if (threadIdx.x == 0)
                 out[k] = s[0];
             __syncthreads();
+        }
+        // device-resident loop without a collective in between: the scalar step that consumes
+        // these sums runs here instead of in a launch of its own (loop_steps.hh)
+        if (threadIdx.x == 0 && loop)
+        {
+            if (tail == kTailSolve)
+                loop_solve_step(loop, out);
+            else if (tail == kTailFinish)
+                loop_finish_step(loop, out);
         }
     }
 
@@ -485,10 +497,10 @@ namespace icp_dev
     }
 
     hipError_t launch_reduce_partials(const double* partials, uint32_t nblocks, int K, double* out,
-                                      hipStream_t s)
+                                      hipStream_t s, LoopState* loop, int tail)
     {
         hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kBlock), 0, s, partials, nblocks,
-                           K, out);
+                           K, out, loop, tail);
         return hipGetLastError();
     }
 

@@ -14,8 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "align3.hh"
 #include "kernels.hh"
+#include "loop_steps.hh"
 
 namespace icp_dev
 {
@@ -50,42 +50,14 @@ namespace icp_dev
 
         __global__ void loop_solve_kernel(LoopState* st, const double* sums)
         {
-            if (threadIdx.x != 0 || blockIdx.x != 0 || st->done)
-                return;
-            float H[9], mu_p[3], mu_m[3], Tn[16], T[16], Tt[16];
-            for (int k = 0; k < 9; ++k)
-                H[k] = (float)sums[k];
-            for (int k = 0; k < 3; ++k)
-            {
-                mu_p[k] = st->mu_p[k];
-                mu_m[k] = st->mu_m[k];
-            }
-            for (int k = 0; k < 16; ++k)
-                T[k] = st->T[k];
-            icp_align::alignment_from_covariance(H, mu_p, mu_m, Tn); // icp.cc:119
-            icp_align::matmul4(Tn, T, Tt);                           // icp.cc:121
-            for (int k = 0; k < 16; ++k)
-                st->T[k] = Tt[k];
-            for (int k = 0; k < 12; ++k)
-                st->Tn[k] = Tn[k];
-            st->work[0] += sums[9];
-            st->work[1] += sums[10];
-            st->work[2] += sums[11];
+            if (threadIdx.x == 0 && blockIdx.x == 0)
+                loop_solve_step(st, sums);
         }
 
         __global__ void loop_finish_kernel(LoopState* st, const double* sums)
         {
-            if (threadIdx.x != 0 || blockIdx.x != 0 || st->done)
-                return;
-            const float error = (float)sums[0];
-            for (int k = 0; k < 3; ++k)
-                st->mu_p[k] = (float)(sums[1 + k] / st->n_total);
-            st->error = error;
-            st->errors[st->it % (uint32_t)kLoopBlockMax] = error;
-            const uint32_t it = st->it + 1u;
-            st->it = it;
-            if (!(it < st->max_iters && error > st->threshold)) // icp.cc:110
-                st->done = 1u;
+            if (threadIdx.x == 0 && blockIdx.x == 0)
+                loop_finish_step(st, sums);
         }
     } // namespace
 

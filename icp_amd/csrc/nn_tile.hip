@@ -773,6 +773,20 @@ namespace icp_dev
                 if (chunk_sums && lane < kCovSums)
                     chunk_sums[(size_t)chunk * kCovSums + lane] = L.sums[lane];
             }
+            // the last workgroup to get here leaves the queue heads zero for the next launch
+            __syncthreads();
+            if (threadIdx.x == 0)
+            {
+                const uint32_t finished = __hip_atomic_fetch_add(queue + 256, 1u, __ATOMIC_ACQ_REL,
+                                                                 __HIP_MEMORY_SCOPE_AGENT);
+                if (finished == gridDim.x - 1u)
+                {
+                    for (uint32_t x = 0; x < 8u; ++x)
+                        __hip_atomic_store(queue + x * 32u, 0u, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(queue + 256, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
             if (STATS && lane == 0)
             {
                 atomicAdd(stats + 0, (unsigned long long)st_batch);
@@ -804,9 +818,6 @@ namespace icp_dev
             return hipErrorInvalidValue;
         const uint32_t n_batches = (a.n + bq - 1) / bq;
         const uint32_t n_chunks = (n_batches + q.chunk_batches - 1) / q.chunk_batches;
-        hipError_t e = hipMemsetAsync(q.queue, 0, kQueueWords * sizeof(uint32_t), s);
-        if (e != hipSuccess)
-            return e;
         if (q.stats)
             hipLaunchKernelGGL(nn_tile_kernel<true>, dim3(a.grid), dim3(kBlock), 0, s, a.tree, a.px,
                                a.py, a.pz, a.mu[0], a.mu[1], a.mu[2], a.n, a.yx, a.yy, a.yz,
