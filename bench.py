@@ -116,6 +116,23 @@ def main():
     if world > 1:
         init_rccl(ctx, world, rank)  # the context's own RCCL communicator (xGMI)
 
+    # achievable streaming bandwidth of this GPU beside the 8 TB/s spec peak: a plain
+    # device-to-device copy of 1 GiB through torch (plumbing), bytes read + written per second
+    copy_gbs = None
+    if rank == 0:
+        src = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 5 * 2.0 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src, dst
+        torch.cuda.empty_cache()
+
     # ---------------- warm-up ----------------
     ctx.set_queries(p_shard, n_total=n_queries_total)
     if args.warmup > 0:
@@ -185,7 +202,10 @@ def main():
                 "valu": {"achieved": round(valu_ach, 2), "peak": round(valu_peak, 2),
                          "unit": "Tflop/s (fp32, no FMA)", "frac": round(valu_ach / valu_peak, 4),
                          "flops_per_launch": round(flops_per_launch)},
-                "stack_spills": tm.get("stack_spills", 0.0)}
+                "stack_spills": tm.get("stack_spills", 0.0),
+                "measured_copy_GBs": round(copy_gbs, 1) if copy_gbs else None,
+                "hbm_traffic_frac_of_copy": (round(traffic / (avg_ms * 1e-3) / 1e9 / copy_gbs, 4)
+                                             if traffic and copy_gbs else None)}
 
     out = None
     if rank == 0:
