@@ -167,21 +167,43 @@ namespace icp_dev
             return v;
         }
 
-        // stable split of every segment + far-point candidates of both children
+        // stable split of every segment + far-point candidates of both children.
+        // Every wave owns a contiguous run of `per_wave` points (a multiple of 64) and keeps the
+        // running maxima of the segment it is in; they go to `best` with one atomic per side when
+        // the wave leaves the segment or ends.  (One atomic per wave-load made the two words of
+        // the root a million-fold contended: 15 ms of a level at 64M points.)
         __global__ void __launch_bounds__(kB)
             scatter_kernel(const uint32_t* __restrict__ seg, const Seg* __restrict__ segs,
                            const SegOut* __restrict__ so, const uint32_t* __restrict__ scan,
                            const uint32_t* __restrict__ flag, const float* __restrict__ d2,
                            const float* __restrict__ x, const float* __restrict__ y,
                            const float* __restrict__ z, const uint32_t* __restrict__ row, uint32_t n,
-                           float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oz,
-                           uint32_t* __restrict__ orow, uint32_t* __restrict__ prov,
-                           unsigned long long* __restrict__ best)
+                           uint32_t per_wave, float* __restrict__ ox, float* __restrict__ oy,
+                           float* __restrict__ oz, uint32_t* __restrict__ orow,
+                           uint32_t* __restrict__ prov, unsigned long long* __restrict__ best)
         {
-            const uint32_t total = (n + kB - 1) / kB * kB;
-            for (uint32_t i = blockIdx.x * kB + threadIdx.x; i < total; i += gridDim.x * kB)
+            const uint32_t lane = threadIdx.x & 63u;
+            const uint32_t wave = (blockIdx.x * kB + threadIdx.x) >> 6;
+            const uint64_t w_begin = (uint64_t)wave * per_wave;
+            if (w_begin >= n)
+                return;
+            const uint32_t w_end = (uint32_t)min((uint64_t)n, w_begin + per_wave);
+            uint32_t run_seg = kDone; // wave-uniform: segment of the pending maxima
+            unsigned long long run_in = 0, run_out = 0;
+            auto flush = [&]() {
+                if (run_seg != kDone && lane == 0)
+                {
+                    if (run_in)
+                        atomicMax(best + 2u * run_seg, run_in);
+                    if (run_out)
+                        atomicMax(best + 2u * run_seg + 1u, run_out);
+                }
+                run_in = run_out = 0;
+            };
+            for (uint32_t base = (uint32_t)w_begin; base < w_end; base += 64u)
             {
-                const bool live = i < n;
+                const uint32_t i = base + lane;
+                const bool live = i < w_end;
                 const uint32_t s = live ? seg[i] : kDone;
                 unsigned long long key_in = 0, key_out = 0;
                 uint32_t child = kDone;
@@ -216,26 +238,33 @@ namespace icp_dev
                     orow[pos] = row[i];
                     prov[pos] = pr;
                 }
-                // one atomic per wave and side when the whole wave sits in one segment
+                // the wave-load lies in one segment (dead lanes of a last, partial load aside)
+                const uint64_t alive = __ballot(live);
                 const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s);
-                if (__all(s == s0))
+                if (__ballot(live && s != s0) == 0ull && alive != 0ull)
                 {
+                    if (s0 != run_seg)
+                    {
+                        flush();
+                        run_seg = s0;
+                    }
                     if (s0 != kDone)
                     {
                         const unsigned long long mi = wave_max_u64(key_in);
                         const unsigned long long mo = wave_max_u64(key_out);
-                        if ((threadIdx.x & 63) == 0)
-                        {
-                            if (mi)
-                                atomicMax(best + 2u * s0, mi);
-                            if (mo)
-                                atomicMax(best + 2u * s0 + 1u, mo);
-                        }
+                        run_in = mi > run_in ? mi : run_in;
+                        run_out = mo > run_out ? mo : run_out;
                     }
                 }
-                else if (child != kDone)
-                    atomicMax(best + child, key_in | key_out);
+                else
+                {
+                    flush();
+                    run_seg = kDone;
+                    if (child != kDone)
+                        atomicMax(best + child, key_in | key_out);
+                }
             }
+            flush();
         }
 
         // the far point of each child goes to the child's last slot (:114-115)
@@ -460,9 +489,13 @@ namespace icp_dev
                                            rocprim::plus<uint32_t>(), st));
             hipLaunchKernelGGL(count_kernel, dim3((S + kB - 1) / kB), dim3(kB), 0, st, segs.p, S,
                                scan.p, segout.p);
-            hipLaunchKernelGGL(scatter_kernel, dim3(grid_n(n)), dim3(kB), 0, st, seg.p, segs.p,
+            // contiguous runs of a multiple of 64 points per wave, every wave of the grid busy
+            const uint32_t sc_grid = grid_n(n);
+            const uint64_t sc_waves = (uint64_t)sc_grid * (kB / 64);
+            const uint32_t per_wave = (uint32_t)(((uint64_t)n + sc_waves * 64 - 1) / (sc_waves * 64)) * 64u;
+            hipLaunchKernelGGL(scatter_kernel, dim3(sc_grid), dim3(kB), 0, st, seg.p, segs.p,
                                segout.p, scan.p, flag.p, d2.p, x[cur].p, y[cur].p, z[cur].p,
-                               row[cur].p, n, x[cur ^ 1].p, y[cur ^ 1].p, z[cur ^ 1].p,
+                               row[cur].p, n, per_wave, x[cur ^ 1].p, y[cur ^ 1].p, z[cur ^ 1].p,
                                row[cur ^ 1].p, prov.p, best.p);
             hipLaunchKernelGGL(swap_kernel, dim3((2 * S + kB - 1) / kB), dim3(kB), 0, st, segs.p,
                                segout.p, S, best.p, x[cur ^ 1].p, y[cur ^ 1].p, z[cur ^ 1].p,
