@@ -284,16 +284,16 @@ namespace
         if (!c->has_tree || !c->has_queries || c->n_local == 0)
             return ICP_HIP_OK;
         // queries per batch: 64 (one per lane) when that fills every resident wave slot; a
-        // smaller shard is cut into narrower batches (32/16/8 queries per wave) so that all
+        // smaller shard is cut into narrower batches (32/16/8/4 queries per wave) so that all
         // SIMDs get work and each wave's serial chain of bucket scans is shorter
         uint32_t bq = 64;
         {
             const char* env = std::getenv("ICP_HIP_BATCH_QUERIES");
             const int forced = env ? std::atoi(env) : 0;
-            if (forced == 64 || forced == 32 || forced == 16 || forced == 8)
+            if (forced == 64 || forced == 32 || forced == 16 || forced == 8 || forced == 4 || forced == 2)
                 bq = (uint32_t)forced;
             else
-                while (bq > 8 && (c->n_local + bq - 1) / bq < (uint64_t)c->tile_blocks * 4)
+                while (bq > 4 && (c->n_local + bq - 1) / bq < (uint64_t)c->tile_blocks * 4)
                     bq >>= 1;
         }
         c->batch_queries = bq;

@@ -95,7 +95,7 @@ namespace icp_dev
     struct TileLaunch
     {
         uint32_t chunk_batches; // batches per chunk (1..8)
-        uint32_t batch_queries; // queries per batch = active lanes per wave: 64, 32, 16 or 8.
+        uint32_t batch_queries; // queries per batch = active lanes per wave: 64, 32, 16, 8, 4 (or 2).
                                 // 64 for large shards; a shard too small to fill the chip is cut
                                 // into narrower batches so that every SIMD gets waves, and the
                                 // idle lanes join the bucket scans as extra parts

@@ -814,7 +814,7 @@ namespace icp_dev
         if (a.height > (uint32_t)kStackK && !q.spill)
             return hipErrorInvalidValue;
         const uint32_t bq = q.batch_queries;
-        if (bq != 64u && bq != 32u && bq != 16u && bq != 8u)
+        if (bq != 64u && bq != 32u && bq != 16u && bq != 8u && bq != 4u && bq != 2u)
             return hipErrorInvalidValue;
         const uint32_t n_batches = (a.n + bq - 1) / bq;
         const uint32_t n_chunks = (n_batches + q.chunk_batches - 1) / q.chunk_batches;

@@ -145,7 +145,7 @@ def test_run_is_bitwise_reproducible():
 
 @pytest.mark.parametrize("n,cap,angle", [(48_000, 32, 6.0), (48_000, 256, 2.0), (700, 16, 10.0)])
 def test_batch_widths_agree(oracle, n, cap, angle):
-    """A shard too small to fill the chip runs 8/16/32 queries per wave instead of 64 (idle lanes
+    """A shard too small to fill the chip runs 4/8/16/32 queries per wave instead of 64 (idle lanes
     join the bucket scans): every width gives the reference's answers, and the work counters of
     the reference traversal do not depend on it."""
     from icp_amd import capi, synth
@@ -155,7 +155,7 @@ def test_batch_widths_agree(oracle, n, cap, angle):
     mu_p = oracle.mean(p)
     want = oracle.tree_closest(oracle.tree_build(cap, mc), oracle.subtract(p, mu_p))
     tree = capi.FlatTree(mc, cap)
-    runs = [_nn(capi, tree, p, mu_p, {"ICP_HIP_BATCH_QUERIES": str(w)}) for w in (64, 32, 16, 8)]
+    runs = [_nn(capi, tree, p, mu_p, {"ICP_HIP_BATCH_QUERIES": str(w)}) for w in (64, 32, 16, 8, 4, 2)]
     for r in runs:
         _same(r, want)
         assert r["timing"]["nodes_visited"] == runs[0]["timing"]["nodes_visited"]
