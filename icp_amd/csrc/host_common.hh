@@ -27,6 +27,9 @@ namespace icp_host
     int build_flat_tree(const float* xyz, uint64_t n, uint32_t capacity, FlatTreeOwner** out,
                         std::string& err);
     int validate_flat_tree(const icp_flat_tree* t, std::string& err);
+    // NaN / infinity anywhere in a[0..count)?  (the search degenerates on them: rejected up front)
+    bool all_finite(const float* a, uint64_t count);
+    extern const char* const kNonFiniteMessage;
     void mean_host(const float* a, uint64_t n, float out[3]);
     void center_host(const float* a, uint64_t n, const float mu[3], float* out);
 

@@ -427,6 +427,9 @@ namespace
             ext = std::fmax(ext, hi[k] - lo[k]);
         const bool finite = std::isfinite(ext) && std::isfinite(lo[0]) && std::isfinite(lo[1]) &&
                             std::isfinite(lo[2]);
+        if (!finite) // the min/max kernel turns a NaN or infinity into an infinite extent
+            return fail(c, ICP_HIP_ERR_ARG,
+                        std::string("icp_hip_set_queries: ") + icp_host::kNonFiniteMessage);
         for (int k = 0; k < 3; ++k)
         {
             scale[k] = (finite && ext > 0.f) ? 1024.f / ext : 0.f;
@@ -1188,6 +1191,9 @@ extern "C"
                                       hipMemcpyHostToDevice, c->stream));
             const char* env = std::getenv("ICP_HIP_SORT_QUERIES");
             const bool want_sort = !(env && env[0] == '0') && n_local >= 1024;
+            if (!want_sort && !icp_host::all_finite(xyz_aos, 3 * n_local))
+                return fail(c, ICP_HIP_ERR_ARG,
+                            std::string("icp_hip_set_queries: ") + icp_host::kNonFiniteMessage);
             if (want_sort)
             {
                 int rc = sort_queries(c, (uint32_t)n_local);

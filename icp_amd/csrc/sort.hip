@@ -42,6 +42,11 @@ namespace icp_dev
                     const float v = aos[3 * (size_t)i + k];
                     lo[k] = fminf(lo[k], v);
                     hi[k] = fmaxf(hi[k], v);
+                    if (!isfinite(v)) // fmin/fmax skip a NaN: make it show (the host rejects it)
+                    {
+                        lo[k] = -INFINITY;
+                        hi[k] = INFINITY;
+                    }
                 }
             for (int k = 0; k < 3; ++k)
             {

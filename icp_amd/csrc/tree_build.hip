@@ -64,13 +64,16 @@ namespace icp_dev
 
         __global__ void __launch_bounds__(kB) init_kernel(const float* __restrict__ aos, uint32_t n,
                                                            float* x, float* y, float* z,
-                                                           uint32_t* row, uint32_t* prov)
+                                                           uint32_t* row, uint32_t* prov,
+                                                           uint32_t* __restrict__ non_finite)
         {
             for (uint32_t i = blockIdx.x * kB + threadIdx.x; i < n; i += gridDim.x * kB)
             {
                 x[i] = aos[3 * (size_t)i];
                 y[i] = aos[3 * (size_t)i + 1];
                 z[i] = aos[3 * (size_t)i + 2];
+                if (!(isfinite(x[i]) && isfinite(y[i]) && isfinite(z[i])))
+                    atomicOr(non_finite, 1u);
                 row[i] = i;
                 prov[i] = 0; // provisional id of the root
             }
@@ -407,9 +410,24 @@ namespace icp_dev
         const size_t tmp_bytes = std::max(tmp_sort, tmp_scan);
         TB_TRY(tmp.alloc(tmp_bytes));
 
+        Buf<uint32_t> non_finite;
+        TB_TRY(non_finite.alloc(1));
+        TB_TRY(hipMemsetAsync(non_finite.p, 0, sizeof(uint32_t), st));
         hipLaunchKernelGGL(init_kernel, dim3(grid_n(n)), dim3(kB), 0, st, d_aos, n, x[0].p, y[0].p,
-                           z[0].p, row[0].p, prov.p);
+                           z[0].p, row[0].p, prov.p, non_finite.p);
         TB_TRY(hipGetLastError());
+        {
+            uint32_t h_bad = 0;
+            TB_TRY(hipMemcpyAsync(&h_bad, non_finite.p, sizeof h_bad, hipMemcpyDeviceToHost, st));
+            TB_TRY(hipStreamSynchronize(st));
+            if (h_bad)
+            {
+                err = "non-finite coordinate (NaN or infinity): every comparison of the "
+                      "reference's search fails on it, so each query would walk the whole tree "
+                      "(vp-tree.cc:147-173)";
+                return 1;
+            }
+        }
 
         // ---- host bookkeeping ----
         struct HNode

@@ -30,6 +30,24 @@
 
 namespace icp_host
 {
+    const char* const kNonFiniteMessage =
+        "non-finite coordinate (NaN or infinity): every comparison of the reference's search fails "
+        "on it, so each query would walk the whole tree (vp-tree.cc:147-173)";
+
+    bool all_finite(const float* a, uint64_t count)
+    {
+        // |x| < inf for every x  <=>  no exponent field is all ones
+        uint32_t bad = 0;
+#pragma omp parallel for reduction(| : bad) if (count > (1u << 20))
+        for (uint64_t i = 0; i < count; ++i)
+        {
+            uint32_t u;
+            std::memcpy(&u, a + i, sizeof u);
+            bad |= ((u & 0x7f800000u) == 0x7f800000u) ? 1u : 0u;
+        }
+        return bad == 0;
+    }
+
     namespace
     {
         struct TmpNode
@@ -195,6 +213,11 @@ namespace icp_host
             err = "icp_hip_tree_build: capacity <= 2 is undefined behaviour in the reference "
                   "(vp-tree.cc:114: empty inside set on 2-point nodes)";
             return ICP_HIP_ERR_DEGENERATE;
+        }
+        if (!all_finite(xyz, 3 * n))
+        {
+            err = "icp_hip_tree_build: " + std::string(kNonFiniteMessage);
+            return ICP_HIP_ERR_ARG;
         }
         Builder b;
         b.pts = xyz;
@@ -399,6 +422,9 @@ namespace icp_host
             (!t->node_cx || !t->node_cy || !t->node_cz || !t->node_radius || !t->node_inside ||
              !t->node_outside || !t->node_parent || !t->node_row))
             return fail("null node array");
+        if (!all_finite(t->node_cx, t->n_nodes) || !all_finite(t->node_cy, t->n_nodes) ||
+            !all_finite(t->node_cz, t->n_nodes) || !all_finite(t->node_radius, t->n_nodes))
+            return fail(kNonFiniteMessage);
         auto code_ok = [&](int32_t c) {
             return c >= 0 ? (uint32_t)c < t->n_nodes : (uint32_t)(~c) < t->n_leaves;
         };
@@ -468,6 +494,10 @@ namespace icp_host
             for (uint32_t k = 0; k < t->leaf_count[l]; ++k)
                 if (t->slot_row[t->leaf_begin[l] + k] >= t->n_points)
                     return fail("slot row out of range");
+            if (!all_finite(t->slot_x + t->leaf_begin[l], t->leaf_count[l]) ||
+                !all_finite(t->slot_y + t->leaf_begin[l], t->leaf_count[l]) ||
+                !all_finite(t->slot_z + t->leaf_begin[l], t->leaf_count[l]))
+                return fail(kNonFiniteMessage);
             pts += t->leaf_count[l];
             max_leaf = std::max(max_leaf, t->leaf_count[l]);
         }

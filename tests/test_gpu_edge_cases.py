@@ -68,3 +68,34 @@ def test_call_order_and_argument_errors(clouds):
         assert it == 1 and np.abs(new_p - m).max() < 5e-3
     with pytest.raises(capi.IcpHipError):
         capi.Context(device_id=4096)
+
+
+@pytest.mark.parametrize("bad", [np.nan, np.inf, -np.inf])
+@pytest.mark.parametrize("n", [300, 5000, 60_000])
+def test_non_finite_coordinates_are_refused(bad, n):
+    """A NaN or infinite coordinate makes every comparison of the reference's search false: each
+    query then walks the whole tree (and one NaN in the cloud to move makes its mean, hence every
+    query, NaN).  The reference would grind through n x n distances; here both clouds are checked
+    up front, whichever way they come in (host build, device build, sorted or unsorted upload)."""
+    from icp_amd import capi, synth
+    m = synth.cloud(n, seed=n)
+    spoiled = m.copy()
+    spoiled[n // 3, 1] = bad
+    mu_m = capi.mean_host(m)
+    mc = capi.center_host(m, mu_m)
+    with capi.Context() as ctx:
+        with pytest.raises(capi.IcpHipError) as e:
+            ctx.build_tree(capi.center_host(spoiled, mu_m), 32)
+        assert e.value.status == 1 and "non-finite" in str(e.value)
+        with pytest.raises(capi.IcpHipError) as e:
+            capi.FlatTree(capi.center_host(spoiled, mu_m), 32)
+        assert e.value.status == 1 and "non-finite" in str(e.value)
+        ctx.build_tree(mc, 32)
+        with pytest.raises(capi.IcpHipError) as e:
+            ctx.set_queries(spoiled)
+        assert e.value.status == 1 and "non-finite" in str(e.value)
+        with pytest.raises(capi.IcpHipError) as e:
+            ctx.icp(m, spoiled, 5, 1e-5, 32)
+        assert e.value.status == 1
+        T, new_p, it, err = ctx.icp(m, m, 5, 1e-5, 32)   # the context is still good
+        assert it == 1 and err <= 1e-5
