@@ -13,7 +13,7 @@
 //  * every chunk writes its own twelve fp64 sums and two small kernels add the chunks in a fixed
 //    order: the result does not depend on which wave ran which chunk (bitwise reproducible);
 //  * the traversal stack holds only the near-side answers of the levels whose far side is being
-//    searched (push on the way into the far side, pop on the way back): 7 entries per lane in
+//    searched (push on the way into the far side, pop on the way back): 4 entries per lane in
 //    LDS instead of one per tree level; deeper nestings spill to a per-lane column in HBM
 //    (counted in sum [11]);
 //  * leaf buckets are scanned by (queries x bucket parts) tiles: the g lanes of a wave that wait

@@ -247,7 +247,7 @@ typedef struct icp_hip_timing {
     double nodes_visited;
     double points_scanned;
     double stack_spills; /* traversal-stack entries that left LDS for HBM (far-side nesting
-                            deeper than the kernel's 7 on-chip entries); diagnostic */
+                            deeper than the kernel's 4 on-chip entries); diagnostic */
 } icp_hip_timing;
 int icp_hip_get_timing(icp_hip_ctx* ctx, icp_hip_timing* out);
 /* NN-kernel milliseconds of each iteration of the last icp_hip_run (first `capacity` entries

@@ -3,7 +3,7 @@
 The parity tests (test_gpu_nn_parity.py) already run on this kernel; here the paths that ordinary
 inputs touch rarely are forced and checked against the oracle / the level-stack kernel:
 
-* the overflow of the 7-entry LDS traversal stack into HBM (deeply nested far-side searches);
+* the overflow of the 4-entry LDS traversal stack into HBM (deeply nested far-side searches);
 * buckets larger than one staged window (> 256 slots) and buckets of a single point;
 * every ordering of the shard (as given, Morton, Morton + leaf order) gives the same answers in
   the caller's order;
