@@ -139,7 +139,8 @@ namespace icp_dev
         __device__ __forceinline__ void tile_scan(const DevTree& t, WaveLds& L, uint32_t beg,
                                                   uint32_t cnt, uint64_t grp, bool member, float qx,
                                                   float qy, float qz, int lane, float& out_m,
-                                                  float& out_m2, uint32_t& out_idx)
+                                                  float& out_m2, uint32_t& out_idx,
+                                                  uint32_t& staged)
         {
             const float kInf = __int_as_float(0x7f800000);
             const uint32_t g = (uint32_t)__builtin_popcountll(grp); // 1..64
@@ -161,7 +162,11 @@ namespace icp_dev
             {
                 const uint32_t cw = min((uint32_t)kImage, cnt - w0);
                 // ---- stage the window: x is +inf in every slot that is not the bucket's ----
+                // (`staged` = first slot of the window the image holds: the batches of a chunk
+                // that share a bucket, and the two halves of a split group, stage it once)
+                if (staged != beg + w0)
                 {
+                    staged = beg + w0;
                     const uint32_t s0 = 4u * (uint32_t)lane;
                     float4 vx = make_float4(kInf, kInf, kInf, kInf);
                     float4 vy = make_float4(0.f, 0.f, 0.f, 0.f), vz = vy;
@@ -381,6 +386,7 @@ namespace icp_dev
                 L.by[kImage + lane] = 0.f;
                 L.bz[kImage + lane] = 0.f;
             }
+            uint32_t staged = 0xFFFFFFFFu; // wave-uniform: window of the bucket image in LDS
             // this lane's column of the overflow stack: entry e at spill_col[e * spill_stride]
             const size_t spill_stride = (size_t)gridDim.x * kBlock;
             uint2* spill_col = spill + (size_t)blockIdx.x * kBlock + threadIdx.x;
@@ -619,7 +625,8 @@ namespace icp_dev
                                 rest &= ~sub;
                                 float m, m2;
                                 uint32_t idx;
-                                tile_scan(t, L, beg, cnt, sub, mem, qx, qy, qz, lane, m, m2, idx);
+                                tile_scan(t, L, beg, cnt, sub, mem, qx, qy, qz, lane, m, m2, idx,
+                                          staged);
                                 if (STATS)
                                 {
                                     st_tile += 1u;
