@@ -267,6 +267,39 @@ def main():
             "nn_queries_per_sec": round(s / (t2 - t1), 1)}
         del otree
         tree.close()
+        # Where the reference's own builder finishes in seconds (<= 4M points; 71 s at 64M), time
+        # the reference itself: its libcpu sources compiled unmodified (oracle/_ref, prebuilt in
+        # the build container) do the tree, mean, subtract, closest and find_covariance; the
+        # Eigen-dependent solve and the two streaming loops behind it come from the port.
+        from oracle import Ref
+        if Ref.available() and n_m <= 4_000_000:
+            ref = Ref()
+            t0 = time.perf_counter()
+            rtree = ref.tree_build(args.capacity, mc)
+            t_rbuild = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            mu_p = ref.mean(sample)
+            q = ref.subtract(sample, mu_p)
+            t1 = time.perf_counter()
+            y = ref.tree_closest(rtree, q)
+            t2 = time.perf_counter()
+            H = ref.find_covariance(q, y)
+            Tn = orc.alignment_from_cov(H, mu_p, mu_m)
+            moved = orc.apply_alignment(sample, Tn)
+            orc.compute_error(y, moved, mu_m)
+            t3 = time.perf_counter()
+            out["cpu_baseline"] = {
+                "value": round(s / (t3 - t0), 1), "unit": "queries/s", "cores": orc.max_threads(),
+                "kind": "reference",
+                "sample": f"one ICP iteration (iteration 0 geometry) of the reference's own libcpu "
+                          f"(compiled unmodified) over the {s} points against its own {n_m}-point "
+                          f"tree (built in {t_rbuild:.2f}s): closest {t2 - t1:.2f}s on "
+                          f"{orc.max_threads()} OpenMP threads, mean/subtract/covariance/solve/"
+                          f"apply/error {(t1 - t0) + (t3 - t2):.2f}s (serial as in the reference; "
+                          f"solve, apply and error from the port: icp.cc needs Eigen)",
+                "nn_queries_per_sec": round(s / (t2 - t1), 1),
+                "port_value": out["cpu_baseline"]["value"]}
+            del rtree
     if rank == 0:
         print(json.dumps(out), flush=True)
     ctx.close()
