@@ -32,9 +32,15 @@ def test_nn_matches_reference_golden(capi, clouds, mname, pname, cap):
         ctx.set_tree(tree)
         ctx.set_queries(p)
         out = ctx.nn(g["mu_p"])  # queries are p - mu_p with the reference's mu_p bits
+        tm = ctx.timing()
     assert (out["row"] == g["row"]).all()
     assert (bits(out["dist"]) == bits(g["dist"])).all()
     assert (bits(out["xyz"]) == bits(mc[g["row"]])).all()
+    # the kernel's work counters are the reference traversal's (they price the algorithmic bytes
+    # of bench.py's roofline block): internal nodes visited, bucket points scanned
+    assert tm["queries"] == len(p)
+    assert tm["nodes_visited"] == float(g["n_int"].astype(np.int64).sum())
+    assert tm["points_scanned"] == float(g["n_pts"].astype(np.int64).sum())
     tree.close()
 
 
@@ -53,12 +59,15 @@ def test_nn_matches_oracle_synthetic(capi, oracle, n, cap, angle):
     q = oracle.subtract(p, mu_p)
     ot = oracle.tree_build(cap, mc)
     assert not oracle.tree_degenerate(ot)
-    want = oracle.tree_closest(ot, q)
+    want = oracle.tree_closest(ot, q, counters=True)
     tree = capi.FlatTree(mc, cap)
     with capi.Context() as ctx:
         ctx.set_tree(tree)
         ctx.set_queries(p)
         out = ctx.nn(mu_p)
+        tm = ctx.timing()
+    assert tm["nodes_visited"] == float(want["n_int"].astype(np.int64).sum())
+    assert tm["points_scanned"] == float(want["n_pts"].astype(np.int64).sum())
     assert (out["row"] == want["row"]).all()
     assert (bits(out["dist"]) == bits(want["dist"])).all()
     assert (bits(out["xyz"]) == bits(want["xyz"])).all()

@@ -5,7 +5,7 @@ bucket contents and order (including the far-point swaps), padding."""
 import numpy as np
 import pytest
 
-from conftest import bits
+from conftest import bits, flat_preorder, golden_nn, tree_sha256
 
 pytestmark = pytest.mark.gpu
 
@@ -48,6 +48,11 @@ def test_reference_clouds(clouds, name, cap):
         dev = ctx.get_tree()
     same_tree(dev, host)
     dev.validate()
+    # directly against the reference: fingerprint of the tree its own compiled libcpu builds
+    pname = {"line_ref": "line_translated_2_3_4", "cow_ref": "cow_tr1", "horse_ref": "horse_tr1"}[name]
+    g = golden_nn(f"nn_{pname}_cap{cap}")
+    assert tree_sha256(flat_preorder(dev)) == str(g["tree_sha256"])
+    assert dev.height == int(g["height"]) and dev.n_leaves == int(g["leaves"])
     dev.close()
     host.close()
 

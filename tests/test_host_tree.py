@@ -5,32 +5,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import NN_GOLDEN, bits, golden_nn
+from conftest import NN_GOLDEN, bits, flat_preorder as preorder, golden_nn, tree_sha256
 from icp_amd import capi, synth
-
-
-def preorder(ft):
-    kind, node_f, node_row, leaf_count, leaf_xyz, leaf_row = [], [], [], [], [], []
-    nc = np.stack([ft.node_cx, ft.node_cy, ft.node_cz, ft.node_radius], 1) if ft.n_nodes else None
-    st = [ft.root]
-    while st:
-        c = st.pop()
-        if c < 0:
-            b, n = int(ft.leaf_begin[~c]), int(ft.leaf_count[~c])
-            kind.append(0)
-            leaf_count.append(n)
-            leaf_xyz.append(np.stack([ft.slot_x[b:b + n], ft.slot_y[b:b + n], ft.slot_z[b:b + n]], 1))
-            leaf_row.append(ft.slot_row[b:b + n])
-        else:
-            kind.append(1)
-            node_f.append(nc[c])
-            node_row.append(ft.node_row[c])
-            st.append(int(ft.node_outside[c]))
-            st.append(int(ft.node_inside[c]))
-    return dict(kind=np.array(kind, np.uint8), node_f=np.array(node_f, np.float32).reshape(-1, 4),
-                node_row=np.array(node_row, np.uint32), leaf_count=np.array(leaf_count, np.uint32),
-                leaf_xyz=np.concatenate(leaf_xyz).astype(np.float32),
-                leaf_row=np.concatenate(leaf_row).astype(np.uint32))
 
 
 def same_tree(ft, oracle, ot):
@@ -53,6 +29,7 @@ def test_builder_and_flat_traversal_on_reference_data(oracle, clouds, mname, pna
     ft = capi.FlatTree(mc, cap)
     ft.validate()
     same_tree(ft, oracle, oracle.tree_build(cap, mc))
+    assert tree_sha256(preorder(ft)) == str(g["tree_sha256"])  # the reference's own tree
     # the kernel's state machine, emulated on the host over the flat layout, gives the
     # reference's answers (golden)
     q = (p - g["mu_p"]).astype(np.float32)
