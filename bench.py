@@ -12,31 +12,36 @@ Metric (BASELINE.json): NN queries/s (+ ICP iterations/s) on synthetic clouds.
 
 A "step" is ONE full ICP iteration over the rank's shard, exactly the reference loop body
 (libcpu/libcpu/icp.cc:110-125): NN of every centred point + 3x3 cross-covariance (one fused
-kernel), all-reduce of the sums (RCCL, N > 1), host SVD solve, apply + error (one fused kernel),
-all-reduce.  Nothing is skipped and nothing is cached between steps.  The timed region is K
-consecutive iterations FROM THE INITIAL misaligned clouds (threshold 0 so the loop cannot exit
-early); the W warm-up iterations run the same thing first and the shard is then re-uploaded
+kernel), solve, apply + error (one fused kernel); with N > 1 ONE all-reduce of 16 doubles per
+iteration over RCCL.  Nothing is skipped and nothing is cached between steps.  The timed region
+is K consecutive iterations FROM THE INITIAL misaligned clouds (threshold 0 so the loop cannot
+exit early); the W warm-up iterations run the same thing first and the shard is then re-uploaded
 (untimed), so inputs are resident in HBM when the clock starts.
 
-Prints ONE JSON line on rank 0.
+Launch: `python bench.py --gpus N` starts its N ranks itself (fresh child processes, made before
+anything in this process has touched a GPU); under torchrun (WORLD_SIZE set) it is one of the
+ranks.  Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+SIMDS = 256 * 4            # 256 CUs x 4 SIMDs
+CLOCK_HZ = 2.4e9           # max clock
+VALU_ISSUE_CYCLES = 2.0    # a wave64 VALU instruction occupies its SIMD-32 for 2 cycles
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -48,21 +53,110 @@ def parse():
     ap.add_argument("--capacity", type=int, default=256)
     ap.add_argument("--angle", type=float, default=None,
                     help="rigid-motion angle in degrees (default 1.0 at <= 8M points, 0.25 above)")
-    ap.add_argument("--cpu-sample", type=int, default=64_000_000,
+    ap.add_argument("--cpu-sample", type=int, default=16_000_000,
                     help="queries of the CPU-baseline sample (0 disables the baseline)")
-    return ap.parse_args()
+    ap.add_argument("--cpu-repeats", type=int, default=0,
+                    help="CPU-baseline repeats (default: 5 at <= 4M points, 3 above; median taken)")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="launcher rehearsal without a GPU: start the ranks, rendezvous over gloo, "
+                         "split the shards, print the line's launch fields and exit")
+    return ap.parse_args(argv)
+
+
+# --------------------------------------------------------------------------------------------
+# launcher: `bench.py --gpus N` without a launcher around it starts N ranks
+# --------------------------------------------------------------------------------------------
+def launch_ranks(n: int) -> int:
+    """Start n fresh rank processes of this script (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in their
+    environment) and wait for them.  This process never touches a GPU and imports no torch."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)]
+                                      + sys.argv[1:], env=env))
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f"bench.py: rank {r} exited with status {code}; stopping the others",
+                      file=sys.stderr, flush=True)
+                for q in alive:   # the ranks we started, by handle: they would hang in a collective
+                    procs[q].terminate()
+        time.sleep(0.05)
+    return rc if rc >= 0 else 1
+
+
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def median(v):
+    v = sorted(v)
+    return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
+
+
+def rehearse(args, rank, world):
+    """The launch path without a GPU: rendezvous (gloo), shard split, a sum over the ranks."""
+    import torch
+    import torch.distributed as dist
+    from icp_amd.dist import shard_bounds
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = args.queries_total or {"64M": 64_000_000, "1M": 1_000_000}.get(args.workload, args.points)
+    b, e = shard_bounds(n, world, rank)
+    t = torch.tensor([float(e - b), 1.0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"rehearsal": True, "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ranks_seen": int(t[1].item()),
+                          "queries_total": int(t[0].item()),
+                          "config": {"queries_per_gpu": e - b,
+                                     "parallelism": f"query-shard x{world}"}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around us: be the launcher (before any torch / HIP call in this process)
+        raise SystemExit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it as "
+                         f"`python bench.py --gpus N` or under a launcher with --nproc-per-node N")
+    if args.rehearse:
+        return rehearse(args, rank, world)
 
+    import numpy as np
     import torch  # device plumbing + torch.distributed only
     import torch.distributed as dist
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank}, but this node has "
+                         f"{torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -159,53 +253,73 @@ def main():
     t_err = float(np.abs(T.astype(np.float64) - want).max())
 
     # ---------------- roofline of the dominant kernel (NN + covariance) ----------------
-    # algorithmic bytes: 12 B query + 4 B result per query, 16 B per internal
-    # node visited, 12 B per bucket point scanned; counted by the kernel itself (its traversal is
-    # bit-identical to the reference's, tests/test_gpu_nn_parity.py checks the counters too).
+    # Measured by this run: the kernel's launch time (HIP events on the library's stream) and its
+    # work counters (internal nodes visited, bucket points scanned; equal to the reference
+    # traversal's, tests/test_gpu_nn_parity.py and tests/test_gpu_64m.py compare them with the
+    # oracle's).  NOT measured by this run: the hardware counters (VALU instructions, HBM bytes);
+    # they come from the committed rocprofv3 --pmc passes of this same command on this kernel
+    # (profiles/nn_counters_<workload>.json, scripts/profile_round.sh) and are labelled so.
+    #
+    # What binds the kernel is VALU issue: the shard is stored in leaf order, the queries of a
+    # wave share buckets, a bucket is staged once in LDS and scanned by (queries x bucket parts)
+    # tiles; `frac` = VALU wave-instructions x 2 cycles / (launch time x 1024 SIMDs x 2.4 GHz).
+    # SURVEY 8d's per-query byte model (16 B per query and per node visited, 12 B per bucket point
+    # scanned) is kept as `algorithmic_GBs`: it charges every query for bucket bytes that ~50
+    # queries share, so it exceeds the HBM peak and is not a fraction of anything.
     launches = max(1, int(tm["nn_launches"]))
     alg_bytes_all = 16.0 * tm["queries"] + 16.0 * tm["nodes_visited"] + 12.0 * tm["points_scanned"]
     bytes_per_launch = alg_bytes_all / launches / world       # one GPU's launch
     avg_ms = tm["nn_ms"] / launches
-    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "nn_traffic.json")
-    if os.path.exists(tpath):
+    avg_s = avg_ms * 1e-3
+    counters, cpath = None, os.path.join("profiles", f"nn_counters_{args.workload}.json")
+    if os.path.exists(os.path.join(ROOT, cpath)):
         try:
-            with open(tpath) as f:
-                tj = json.load(f)
-            if tj.get("workload") == args.workload and tj.get("n_gpus", 1) == 1:
-                traffic = tj.get("hbm_bytes_per_launch")
+            with open(os.path.join(ROOT, cpath)) as f:
+                cj = json.load(f)
+            if cj.get("workload") == args.workload and cj.get("n_gpus", 1) == world == 1 and \
+                    cj.get("steps") == args.steps and cj.get("warmup") == args.warmup:
+                counters = cj
         except Exception:
-            traffic = None
-    # Reading the fraction: the algorithmic bytes charge every query for the bucket points and
-    # nodes ITS traversal reads.  The shard is stored in leaf order, so the queries of
-    # a wave share buckets, which the tile scan stages once in LDS: achieved can exceed the HBM
-    # peak; `traffic` (HBM bytes per launch from the FETCH_SIZE/WRITE_SIZE passes under
-    # profiles/) is what actually crosses the memory interface.  The kernel is then bound by
-    # VALU issue: `valu` prices the traversal's fp32 operations (8 per distance: 3 sub, 3 mul,
-    # 2 add, never contracted to FMA because the answers must be the reference's bit for bit)
-    # against the non-FMA vector rate, 256 CUs x 128 lanes x 2.4 GHz.
+            counters = None
     n_gpu = float(end - begin)
     tree_bytes = 12.0 * tinfo["n_slots"] + 32.0 * tinfo["n_nodes"]
     compulsory = 16.0 * n_gpu + min(tree_bytes, bytes_per_launch)
     flops_per_launch = 8.0 * (tm["points_scanned"] + tm["nodes_visited"]) / launches / world
-    valu_peak = 256 * 128 * 2.4e9 / 1e12
-    valu_ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
-    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": "nn_tile_kernel", "avg_launch_ms": round(avg_ms, 4),
-                "launches": launches, "algorithmic_bytes_per_launch": round(bytes_per_launch),
+    flop_peak = 256 * 128 * CLOCK_HZ / 1e12    # fp32 lanes x clock: the rate without FMA
+    flop_ach = flops_per_launch / avg_s / 1e12
+    issue_peak = SIMDS * CLOCK_HZ / VALU_ISSUE_CYCLES / 1e9   # G wave-instructions / s
+    roofline = {"kernel": "nn_tile_kernel", "avg_launch_ms": round(avg_ms, 4), "launches": launches,
+                "traffic": None, "hbm": None, "counters_from": None,
+                "fp32_no_fma": {"achieved": round(flop_ach, 2), "peak": round(flop_peak, 2),
+                                "unit": "TFLOP/s", "frac": round(flop_ach / flop_peak, 4),
+                                "note": "8 flops per distance (3 sub, 3 mul, 2 add; never "
+                                        "contracted: the answers must round like the reference's)"},
+                "algorithmic_GBs": round(bytes_per_launch / avg_s / 1e9, 1),
+                "algorithmic_bytes_per_launch": round(bytes_per_launch),
                 "bytes_per_query": round(alg_bytes_all / max(1.0, tm["queries"]), 1),
                 "compulsory_bytes_per_launch": round(compulsory),
-                "hbm_traffic_frac": (round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-                                     if traffic else None),
-                "valu": {"achieved": round(valu_ach, 2), "peak": round(valu_peak, 2),
-                         "unit": "Tflop/s (fp32, no FMA)", "frac": round(valu_ach / valu_peak, 4),
-                         "flops_per_launch": round(flops_per_launch)},
                 "stack_spills": tm.get("stack_spills", 0.0),
-                "measured_copy_GBs": round(copy_gbs, 1) if copy_gbs else None,
-                "hbm_traffic_frac_of_copy": (round(traffic / (avg_ms * 1e-3) / 1e9 / copy_gbs, 4)
-                                             if traffic and copy_gbs else None)}
+                "measured_copy_GBs": round(copy_gbs, 1) if copy_gbs else None}
+    if counters:
+        valu = float(counters["valu_insts_per_launch"])
+        traffic = float(counters["hbm_bytes_per_launch"])
+        ach = valu / avg_s / 1e9
+        roofline.update({
+            "bound": "valu_issue", "achieved": round(ach, 1), "peak": round(issue_peak, 1),
+            "unit": "G wave-instr/s", "frac": round(ach / issue_peak, 4),
+            "traffic": round(traffic),
+            "hbm": {"achieved": round(traffic / avg_s / 1e9, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4),
+                    "frac_of_measured_copy": (round(traffic / avg_s / 1e9 / copy_gbs, 4)
+                                              if copy_gbs else None),
+                    "traffic_over_compulsory": round(traffic / compulsory, 2)},
+            "counters_from": f"{cpath}: rocprofv3 --pmc passes of this command by the builder "
+                             f"({counters.get('tag', '?')}), not measured by this run"})
+    else:
+        # no counter file for this command: fall back to the arithmetic the traversal must do
+        roofline.update({"bound": "valu_fp32_no_fma", "achieved": round(flop_ach, 2),
+                         "peak": round(flop_peak, 2), "unit": "TFLOP/s",
+                         "frac": round(flop_ach / flop_peak, 4)})
 
     out = None
     if rank == 0:
@@ -223,9 +337,13 @@ def main():
                        "queries_per_gpu": end - begin, "capacity": args.capacity,
                        "tree_height": int(tinfo["height"]), "parallelism": f"query-shard x{world}"},
             "icp_iterations_per_sec": round(args.steps / dt, 3),
-            "nn_kernel_queries_per_sec": round((end - begin) * world / (avg_ms * 1e-3), 1),
+            "nn_kernel_queries_per_sec": round((end - begin) * world / avg_s, 1),
             "nn_ms_first_iter": round(float(trace[0]), 4) if len(trace) else None,
             "nn_ms_last_iter": round(float(trace[-1]), 4) if len(trace) else None,
+            "nn_queries_per_sec_first_iter": (round((end - begin) * world / (float(trace[0]) * 1e-3), 1)
+                                              if len(trace) and trace[0] > 0 else None),
+            "nn_queries_per_sec_last_iter": (round((end - begin) * world / (float(trace[-1]) * 1e-3), 1)
+                                             if len(trace) and trace[-1] > 0 else None),
             "phase_ms_per_step": {"nn_cov": round(tm["nn_ms"] / launches, 4),
                                   "apply_error": round(tm["apply_ms"] / launches, 4),
                                   "host_loop": round(tm["host_ms"] / launches, 4)},
@@ -236,70 +354,68 @@ def main():
         }
 
     # ---------------- CPU baseline beside it (rank 0, N == 1 only) ----------------
+    # One libcpu iteration on a bounded sample of the shard against the same tree, on the box's
+    # host cores: median of >= 3 repeats (>= 5 at 1M), on the geometry of iteration 0 (`value`,
+    # next to nn_ms_first_iter) and on the converged geometry (next to nn_ms_last_iter).
     if rank == 0 and world == 1 and args.cpu_sample > 0:
-        from oracle import Oracle  # the checker, timed as the "port" baseline -- never the product
+        from oracle import Oracle, Ref  # the checker, timed as the baseline -- never the product
         orc = Oracle()
         s = min(args.cpu_sample, end - begin)
+        reps = args.cpu_repeats or (5 if n_m <= 4_000_000 else 3)
         sample = np.ascontiguousarray(p_shard[:s])
+        aligned = synth.apply_fp32(sample, want.astype(np.float32))  # the converged cloud
+        use_ref = Ref.available() and n_m <= 4_000_000
+        # Where the reference's own builder finishes in seconds (<= 4M points; 71 s at 64M) the
+        # baseline is the reference itself: its libcpu sources compiled unmodified (oracle/_ref,
+        # prebuilt in the build container) do the tree, mean, subtract, closest and
+        # find_covariance; the Eigen-dependent solve and the two streaming loops behind it come
+        # from the port.  Above that the port (oracle/, bit-identical answers) does all of it.
         t0 = time.perf_counter()
-        tree = capi.FlatTree(mc, args.capacity)   # host build of the same tree for the CPU walk
-        out["setup_s"]["tree_build_host"] = round(time.perf_counter() - t0, 2)
-        otree = orc.tree_from_flat(tree)
-        t0 = time.perf_counter()
-        mu_p = orc.mean(sample)
-        q = orc.subtract(sample, mu_p)
-        t1 = time.perf_counter()
-        y = orc.tree_closest(otree, q)["xyz"]
-        t2 = time.perf_counter()
-        H = orc.find_covariance(q, y)
-        Tn = orc.alignment_from_cov(H, mu_p, mu_m)
-        moved = orc.apply_alignment(sample, Tn)
-        orc.compute_error(y, moved, mu_m)
-        t3 = time.perf_counter()
-        out["cpu_baseline"] = {
-            "value": round(s / (t3 - t0), 1), "unit": "queries/s", "cores": orc.max_threads(),
-            "kind": "port",
-            "sample": f"one libcpu-equivalent ICP iteration (iteration 0 geometry) over the first "
-                      f"{s} points of the shard against the same {n_m}-point tree: "
-                      f"NN {t2 - t1:.2f}s on {orc.max_threads()} OpenMP threads, "
-                      f"mean/subtract/covariance/apply/error {(t1 - t0) + (t3 - t2):.2f}s "
-                      f"(serial as in the reference)",
-            "nn_queries_per_sec": round(s / (t2 - t1), 1)}
-        del otree
-        tree.close()
-        # Where the reference's own builder finishes in seconds (<= 4M points; 71 s at 64M), time
-        # the reference itself: its libcpu sources compiled unmodified (oracle/_ref, prebuilt in
-        # the build container) do the tree, mean, subtract, closest and find_covariance; the
-        # Eigen-dependent solve and the two streaming loops behind it come from the port.
-        from oracle import Ref
-        if Ref.available() and n_m <= 4_000_000:
+        if use_ref:
             ref = Ref()
+            tree = ref.tree_build(args.capacity, mc)
+            eng, closest = ref, (lambda q: ref.tree_closest(tree, q))
+        else:
+            ftree = capi.FlatTree(mc, args.capacity)   # host build of the same tree
+            tree = orc.tree_from_flat(ftree)
+            eng, closest = orc, (lambda q: orc.tree_closest(tree, q)["xyz"])
+        t_tree = time.perf_counter() - t0
+
+        def one_iteration(cloud):
             t0 = time.perf_counter()
-            rtree = ref.tree_build(args.capacity, mc)
-            t_rbuild = time.perf_counter() - t0
-            t0 = time.perf_counter()
-            mu_p = ref.mean(sample)
-            q = ref.subtract(sample, mu_p)
+            mu_p = eng.mean(cloud)
+            q = eng.subtract(cloud, mu_p)
             t1 = time.perf_counter()
-            y = ref.tree_closest(rtree, q)
+            y = closest(q)
             t2 = time.perf_counter()
-            H = ref.find_covariance(q, y)
+            H = eng.find_covariance(q, y)
             Tn = orc.alignment_from_cov(H, mu_p, mu_m)
-            moved = orc.apply_alignment(sample, Tn)
+            moved = orc.apply_alignment(cloud, Tn)
             orc.compute_error(y, moved, mu_m)
             t3 = time.perf_counter()
-            out["cpu_baseline"] = {
-                "value": round(s / (t3 - t0), 1), "unit": "queries/s", "cores": orc.max_threads(),
-                "kind": "reference",
-                "sample": f"one ICP iteration (iteration 0 geometry) of the reference's own libcpu "
-                          f"(compiled unmodified) over the {s} points against its own {n_m}-point "
-                          f"tree (built in {t_rbuild:.2f}s): closest {t2 - t1:.2f}s on "
-                          f"{orc.max_threads()} OpenMP threads, mean/subtract/covariance/solve/"
-                          f"apply/error {(t1 - t0) + (t3 - t2):.2f}s (serial as in the reference; "
-                          f"solve, apply and error from the port: icp.cc needs Eigen)",
-                "nn_queries_per_sec": round(s / (t2 - t1), 1),
-                "port_value": out["cpu_baseline"]["value"]}
-            del rtree
+            return t3 - t0, t2 - t1
+
+        first = [one_iteration(sample) for _ in range(reps)]
+        last = [one_iteration(aligned) for _ in range(reps)]
+        it_first, nn_first = median([a for a, _ in first]), median([b for _, b in first])
+        it_last, nn_last = median([a for a, _ in last]), median([b for _, b in last])
+        threads = orc.max_threads()
+        out["cpu_baseline"] = {
+            "value": round(s / it_first, 1), "unit": "queries/s", "cores": threads,
+            "cpu_model": cpu_model(), "kind": "reference" if use_ref else "port",
+            "repeats": reps,
+            "sample": f"one ICP iteration of "
+                      f"{'the reference libcpu (compiled unmodified)' if use_ref else 'the libcpu port (oracle/)'}"
+                      f" over the first {s} points of the shard against the same {n_m}-point tree, "
+                      f"median of {reps}: closest() on {threads} OpenMP threads, mean / subtract / "
+                      f"covariance / solve / apply / error serial as in the reference; `value` is "
+                      f"on the iteration-0 geometry",
+            "nn_queries_per_sec_first_iter": round(s / nn_first, 1),
+            "nn_queries_per_sec_last_iter": round(s / nn_last, 1),
+            "iteration_queries_per_sec_last_iter": round(s / it_last, 1),
+            "tree_build_s": round(t_tree, 2)}
+        out["setup_s"]["tree_build_cpu_baseline"] = round(t_tree, 2)
+        del tree
     if rank == 0:
         print(json.dumps(out), flush=True)
     ctx.close()

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -18,6 +19,7 @@
 #include "host_common.hh"
 #include "icp_hip.h"
 #include "kernels.hh"
+#include "loop_steps.hh"
 #include "tree_build.hh"
 
 using namespace icp_dev;
@@ -228,26 +230,32 @@ namespace
         return ms;
     }
 
-    // Sum `count` doubles over all shards.  dev -> (RCCL on the stream | host callback) -> host.
-    int reduce_to_host(icp_hip_ctx* c, int count)
+    // c->sums[first, first + count) -> c->h_sums (same offsets), waited for
+    int sums_to_host(icp_hip_ctx* c, int first, int count)
     {
-        if (c->comm)
-        {
-            int rc = g_rccl.AllReduce(c->sums.p, c->sums.p, (size_t)count, Rccl::kDouble,
-                                      Rccl::kSum, c->comm, c->stream);
-            if (rc != 0)
-                return fail(c, ICP_HIP_ERR_COMM,
-                            std::string("ncclAllReduce: ") +
-                                (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"));
-        }
-        HIP_TRY(c, hipMemcpyAsync(c->h_sums, c->sums.p, sizeof(double) * count,
+        HIP_TRY(c, hipMemcpyAsync(c->h_sums + first, c->sums.p + first, sizeof(double) * count,
                                   hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (!c->comm && c->allreduce)
-        {
-            if (c->allreduce(c->h_sums, count, c->allreduce_user) != 0)
-                return fail(c, ICP_HIP_ERR_COMM, "all-reduce callback failed");
-        }
+        return ICP_HIP_OK;
+    }
+
+    // Sum c->sums[first, first + count) over all ranks, in place, on the context's stream (RCCL).
+    int rccl_allreduce(icp_hip_ctx* c, int first, int count)
+    {
+        const int rc = g_rccl.AllReduce(c->sums.p + first, c->sums.p + first, (size_t)count,
+                                        Rccl::kDouble, Rccl::kSum, c->comm, c->stream);
+        if (rc != 0)
+            return fail(c, ICP_HIP_ERR_COMM,
+                        std::string("ncclAllReduce: ") +
+                            (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"));
+        return ICP_HIP_OK;
+    }
+
+    // Sum c->h_sums[first, first + count) over all shards through the caller's callback.
+    int host_allreduce(icp_hip_ctx* c, int first, int count)
+    {
+        if (c->allreduce && c->allreduce(c->h_sums + first, count, c->allreduce_user) != 0)
+            return fail(c, ICP_HIP_ERR_COMM, "all-reduce callback failed");
         return ICP_HIP_OK;
     }
 
@@ -323,61 +331,75 @@ namespace
         return ICP_HIP_OK;
     }
 
-    // One NN + covariance pass over the shard.  Leaves the kCovSums sums (all-reduced over the
-    // shards when `allreduce`) in c->h_sums and the kernel time in *ms.
-    int nn_pass(icp_hip_ctx* c, NnLaunch a, bool allreduce, float* ms)
+    // Enqueue one NN + covariance pass over the shard and the reduction of its kCovSums sums into
+    // c->sums[0 .. kCovSums) (this shard only; nothing is waited for).  `a.loop` set: the pass of
+    // the device-resident loop (`tail` = the loop step that rides on the last reduction).
+    // e0 / e1 (may be null) are recorded around the NN kernel.
+    int enqueue_nn(icp_hip_ctx* c, NnLaunch a, int tail, hipEvent_t e0, hipEvent_t e1)
     {
+        LoopState* loop = a.loop ? c->loop_state : nullptr;
+        if (c->n_local == 0)
+        {
+            // an empty shard (more ranks than points) adds nothing
+            HIP_TRY(c, hipMemsetAsync(c->sums.p, 0, sizeof(double) * kCovSums, c->stream));
+            return ICP_HIP_OK;
+        }
         const bool deep = c->force_deep || !c->tile_ready;
-        *ms = 0.f;
         if (deep)
         {
             a.grid = nn_grid(c->n_local);
-            HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+            if (e0)
+                HIP_TRY(c, hipEventRecord(e0, c->stream));
             HIP_TRY(c, launch_nn(a, c->stream));
-            HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-            HIP_TRY(c, launch_reduce_partials(c->partials.p, a.grid, kCovSums, c->sums.p, c->stream));
+            if (e1)
+                HIP_TRY(c, hipEventRecord(e1, c->stream));
+            HIP_TRY(c, launch_reduce_partials(c->partials.p, a.grid, kCovSums, c->sums.p, c->stream,
+                                              loop, tail));
+            return ICP_HIP_OK;
         }
-        else
+        a.grid = c->tile_grid_blocks;
+        TileLaunch q{c->chunk_batches, c->batch_queries, c->chunk_sums.p, c->queue.p,
+                     c->spill.p, loop ? nullptr : c->stats.p, c->tile_cut};
+        if (q.stats)
+            HIP_TRY(c, hipMemsetAsync(q.stats, 0, 8 * sizeof(unsigned long long), c->stream));
+        if (e0)
+            HIP_TRY(c, hipEventRecord(e0, c->stream));
+        HIP_TRY(c, launch_nn_tile(a, q, c->stream));
+        if (e1)
+            HIP_TRY(c, hipEventRecord(e1, c->stream));
+        if (q.stats)
         {
-            a.grid = c->tile_grid_blocks;
-            TileLaunch q{c->chunk_batches, c->batch_queries, c->chunk_sums.p, c->queue.p,
-                         c->spill.p, c->stats.p, c->tile_cut};
-            if (c->stats.p)
-                HIP_TRY(c, hipMemsetAsync(c->stats.p, 0, 8 * sizeof(unsigned long long), c->stream));
-            HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-            HIP_TRY(c, launch_nn_tile(a, q, c->stream));
-            HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-            if (c->stats.p)
-            {
-                unsigned long long h[8];
-                HIP_TRY(c, hipMemcpyAsync(h, c->stats.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
-                HIP_TRY(c, hipStreamSynchronize(c->stream));
-                std::fprintf(stderr,
-                             "[tile stats] batches %llu node_iters %llu node_lane_steps %llu "
-                             "leaf_phases %llu tile_scans %llu tile_lanes %llu coop_scans %llu "
-                             "exact_scans %llu\n",
-                             h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
-            }
-            // chunk sums -> <= 1024 partial rows -> the twelve sums, both in a fixed order
-            uint32_t g1 = (c->n_chunks + 63) / 64;
-            g1 = g1 > 1024 ? 1024 : g1;
-            HIP_TRY(c, launch_reduce_rows(c->chunk_sums.p, c->n_chunks, kCovSums, g1, c->partials.p,
-                                          c->stream));
-            HIP_TRY(c, launch_reduce_partials(c->partials.p, g1, kCovSums, c->sums.p, c->stream));
-        }
-        if (allreduce)
-        {
-            int rc = reduce_to_host(c, kCovSums);
-            if (rc != ICP_HIP_OK)
-                return rc;
-        }
-        else
-        {
-            HIP_TRY(c, hipMemcpyAsync(c->h_sums, c->sums.p, sizeof(double) * kCovSums,
-                                      hipMemcpyDeviceToHost, c->stream));
+            unsigned long long h[8];
+            HIP_TRY(c, hipMemcpyAsync(h, q.stats, sizeof h, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
+            std::fprintf(stderr,
+                         "[tile stats] batches %llu node_iters %llu node_lane_steps %llu "
+                         "leaf_phases %llu tile_scans %llu tile_lanes %llu coop_scans %llu "
+                         "exact_scans %llu\n",
+                         h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
         }
-        *ms = elapsed_ms(c);
+        // chunk sums -> <= 1024 partial rows -> the twelve sums, both in a fixed order
+        uint32_t g1 = (c->n_chunks + 63) / 64;
+        g1 = g1 > 1024 ? 1024 : g1;
+        HIP_TRY(c, launch_reduce_rows(c->chunk_sums.p, c->n_chunks, kCovSums, g1, c->partials.p,
+                                      c->stream));
+        HIP_TRY(c, launch_reduce_partials(c->partials.p, g1, kCovSums, c->sums.p, c->stream, loop,
+                                          tail));
+        return ICP_HIP_OK;
+    }
+
+    // One NN + covariance pass over the shard, waited for: its kCovSums sums (this shard) in
+    // c->h_sums and the kernel time in *ms.
+    int nn_pass(icp_hip_ctx* c, NnLaunch a, float* ms)
+    {
+        *ms = 0.f;
+        int rc = enqueue_nn(c, a, kTailNone, c->ev0, c->ev1);
+        if (rc != ICP_HIP_OK)
+            return rc;
+        if ((rc = sums_to_host(c, 0, kCovSums)) != ICP_HIP_OK)
+            return rc;
+        if (c->n_local)
+            *ms = elapsed_ms(c);
         return ICP_HIP_OK;
     }
 
@@ -571,154 +593,266 @@ namespace
         return prepare_tile(c);
     }
 
-    // One iteration of the device-resident loop, enqueued without waiting for anything:
-    // NN + covariance, its sums, the solve, apply + error, its sums, the loop condition.
-    int enqueue_iteration(icp_hip_ctx* c, hipEvent_t* ev)
+    // One slot of the device-resident loop, enqueued without waiting for anything.
+    //   one GPU:  NN + covariance, its sums (+ solve), apply + error, its sums (+ loop condition)
+    //   RCCL:     NN + covariance, its sums, ONE all-reduce of the kIterSums doubles (this pass'
+    //             sums and the apply pass' sums of the iteration before), advance (loop condition
+    //             of the iteration before, then this one's solve), apply + error, its sums
+    int enqueue_slot(icp_hip_ctx* c, hipEvent_t* ev)
     {
         const uint32_t n = (uint32_t)c->n_local;
         const float zero[3] = {0.f, 0.f, 0.f};
+        const bool sharded = c->comm != nullptr;
         NnLaunch a = make_nn(c, zero, true, false, false, true);
         a.loop = c->loop_state;
-        a.grid = c->tile_grid_blocks;
-        TileLaunch q{c->chunk_batches, c->batch_queries, c->chunk_sums.p, c->queue.p,
-                     c->spill.p, nullptr, c->tile_cut};
-        const bool timed = c->phase_timers; // an event costs ~5 us of stream time
-        if (timed)
-            HIP_TRY(c, hipEventRecord(ev[0], c->stream));
-        HIP_TRY(c, launch_nn_tile(a, q, c->stream));
-        if (timed)
-            HIP_TRY(c, hipEventRecord(ev[1], c->stream));
-        uint32_t g1 = (c->n_chunks + 63) / 64;
-        g1 = g1 > 1024 ? 1024 : g1;
-        HIP_TRY(c, launch_reduce_rows(c->chunk_sums.p, c->n_chunks, kCovSums, g1, c->partials.p,
-                                      c->stream));
-        // without a collective in between, the solve rides on the launch that makes its sums
-        HIP_TRY(c, launch_reduce_partials(c->partials.p, g1, kCovSums, c->sums.p, c->stream,
-                                          c->loop_state, c->comm ? kTailNone : kTailSolve));
-        auto allreduce = [&](int count) -> int {
-            if (!c->comm)
-                return ICP_HIP_OK;
-            const int rc = g_rccl.AllReduce(c->sums.p, c->sums.p, (size_t)count, Rccl::kDouble,
-                                            Rccl::kSum, c->comm, c->stream);
-            if (rc != 0)
-                return fail(c, ICP_HIP_ERR_COMM,
-                            std::string("ncclAllReduce: ") +
-                                (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"));
-            return ICP_HIP_OK;
-        };
-        int rc = allreduce(kCovSums);
+        int rc = enqueue_nn(c, a, sharded ? kTailNone : kTailSolve, ev ? ev[0] : nullptr,
+                            ev ? ev[1] : nullptr);
         if (rc != ICP_HIP_OK)
             return rc;
-        if (c->comm)
-            HIP_TRY(c, launch_loop_solve(c->loop_state, c->sums.p, c->stream));
+        if (sharded)
+        {
+            if ((rc = rccl_allreduce(c, 0, kIterSums)) != ICP_HIP_OK)
+                return rc;
+            HIP_TRY(c, launch_loop_advance(c->loop_state, c->sums.p, c->stream));
+        }
+        if (n == 0)
+        {
+            HIP_TRY(c, hipMemsetAsync(c->sums.p + kApplyAt, 0, sizeof(double) * kApplySums,
+                                      c->stream));
+            return ICP_HIP_OK;
+        }
         const uint32_t g_st = stream_grid(n);
         Mat34 unused{};
-        if (timed)
+        if (ev)
             HIP_TRY(c, hipEventRecord(ev[2], c->stream));
         HIP_TRY(c, launch_apply_error(c->px.p, c->py.p, c->pz.p, c->yx.p, c->yy.p, c->yz.p, unused,
                                       zero, n, g_st, c->partials.p, c->loop_state, c->stream));
-        if (timed)
+        if (ev)
             HIP_TRY(c, hipEventRecord(ev[3], c->stream));
-        HIP_TRY(c, launch_reduce_partials(c->partials.p, g_st, kApplySums, c->sums.p, c->stream,
-                                          c->loop_state, c->comm ? kTailNone : kTailFinish));
-        if ((rc = allreduce(kApplySums)) != ICP_HIP_OK)
-            return rc;
-        if (c->comm)
-            HIP_TRY(c, launch_loop_finish(c->loop_state, c->sums.p, c->stream));
+        HIP_TRY(c, launch_reduce_partials(c->partials.p, g_st, kApplySums, c->sums.p + kApplyAt,
+                                          c->stream, c->loop_state,
+                                          sharded ? kTailNone : kTailFinish));
         return ICP_HIP_OK;
     }
 
-    // libcpu::icp's loop (icp.cc:110-125) with the host out of the iteration: iterations are
-    // enqueued in blocks of 1, 2, 4, 8, 8, .. and the state is read back once per block; what was
-    // enqueued past the end of the loop finds `done` set and does nothing.  With an RCCL
-    // communicator the block is one iteration, so that every rank issues the same collectives
-    // whichever loop it runs.
+    // The centroid sums of the cloud as uploaded -> c->sums[kApplyAt ..) (this shard; enqueued)
+    int enqueue_first_sums(icp_hip_ctx* c)
+    {
+        const uint32_t n = (uint32_t)c->n_local;
+        if (n == 0)
+        {
+            HIP_TRY(c, hipMemsetAsync(c->sums.p + kApplyAt, 0, sizeof(double) * kApplySums,
+                                      c->stream));
+            return ICP_HIP_OK;
+        }
+        const uint32_t g_st = stream_grid(n);
+        HIP_TRY(c, launch_sum_points(c->px.p, c->py.p, c->pz.p, n, g_st, c->partials.p, c->stream));
+        HIP_TRY(c, launch_reduce_partials(c->partials.p, g_st, kApplySums, c->sums.p + kApplyAt,
+                                          c->stream));
+        return ICP_HIP_OK;
+    }
+
+    void loop_results(icp_hip_ctx* c, const LoopState& st, float T_out[16], uint64_t* iters_done,
+                      float* final_error)
+    {
+        std::memcpy(T_out, st.T, sizeof st.T);
+        if (iters_done)
+            *iters_done = st.it;
+        if (final_error)
+            *final_error = st.error;
+        c->timing.nodes_visited += st.work[0];
+        c->timing.points_scanned += st.work[1];
+        c->timing.stack_spills += st.work[2];
+    }
+
+    // libcpu::icp's loop (icp.cc:110-125) with the host out of the iteration: slots are enqueued
+    // in blocks of 1, 2, 4, 8, 8, .. and the state is read back once per block; what was enqueued
+    // past the end of the loop finds `done` set and does nothing.  Sharded over RCCL ranks the
+    // loop condition of an iteration is known one slot later (it rides on the next all-reduce),
+    // so a run of k iterations takes k + 1 slots; the NN pass of the extra slot is skipped on the
+    // device when k is the iteration cap and is discarded otherwise.  Every rank reads the same
+    // state bits after the all-reduce, hence enqueues the same slots and the same collectives.
     int run_device_loop(icp_hip_ctx* c, const float mu_m[3], uint64_t max_iters, float threshold,
                         float T_out[16], uint64_t* iters_done, float* final_error,
                         icp_hip_progress_fn progress, void* user)
     {
         const auto t_begin = std::chrono::steady_clock::now();
+        c->nn_trace.clear();
+        const uint32_t cap_iters = max_iters > 0xFFFFFFFEull ? 0xFFFFFFFEu : (uint32_t)max_iters;
+        const bool sharded = c->comm != nullptr;
+        int rc;
+        // first mean(p) (icp.cc:114); T = I, error = +inf (:101-104)
+        if ((rc = enqueue_first_sums(c)) != ICP_HIP_OK)
+            return rc;
+        if (sharded && (rc = rccl_allreduce(c, kApplyAt, kApplySums)) != ICP_HIP_OK)
+            return rc;
+        HIP_TRY(c, launch_loop_init(c->loop_state, c->sums.p + kApplyAt, mu_m, threshold, cap_iters,
+                                    (double)c->n_total, c->stream));
+        const uint32_t slots_cap = cap_iters == 0 ? 0u : cap_iters + (sharded ? 1u : 0u);
+        uint32_t slots = 0, it_done = 0, block = 1;
+        std::vector<float> slot_nn, slot_ap; // kernel times by slot (slot i holds iteration i)
+        bool done = cap_iters == 0 || !(std::numeric_limits<float>::infinity() > threshold);
+        while (!done && slots < slots_cap)
+        {
+            const uint32_t B = std::min(block, slots_cap - slots);
+            while (c->phase_timers && c->loop_events.size() < (size_t)4 * B)
+            {
+                hipEvent_t ev = nullptr;
+                HIP_TRY(c, hipEventCreate(&ev));
+                c->loop_events.push_back(ev);
+            }
+            for (uint32_t s = 0; s < B; ++s)
+                if ((rc = enqueue_slot(c, c->phase_timers ? c->loop_events.data() + 4 * s
+                                                          : nullptr)) != ICP_HIP_OK)
+                    return rc;
+            HIP_TRY(c, hipMemcpyAsync(c->h_loop, c->loop_state, sizeof(LoopState),
+                                      hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            const LoopState& st = *c->h_loop;
+            for (uint32_t s = 0; s < B; ++s)
+            {
+                float nn_ms = 0.f, ap_ms = 0.f;
+                // a slot past the end of the loop still records its events: nothing ran between
+                if (c->phase_timers && c->n_local)
+                {
+                    hipEvent_t* ev = c->loop_events.data() + 4 * s;
+                    (void)hipEventElapsedTime(&nn_ms, ev[0], ev[1]);
+                    (void)hipEventElapsedTime(&ap_ms, ev[2], ev[3]);
+                }
+                slot_nn.push_back(nn_ms);
+                slot_ap.push_back(ap_ms);
+            }
+            slots += B;
+            for (uint32_t i = it_done; i < st.it; ++i)
+            {
+                c->timing.nn_ms += slot_nn[i];
+                c->timing.apply_ms += slot_ap[i];
+                c->timing.nn_launches += 1;
+                c->timing.queries += (double)c->n_total;
+                if (c->phase_timers && c->nn_trace.size() < 4096)
+                    c->nn_trace.push_back(slot_nn[i]);
+                if (progress)
+                    progress(i + 1, max_iters, st.errors[i % (uint32_t)kLoopBlockMax], user);
+            }
+            it_done = st.it;
+            done = st.done != 0;
+            block = std::min(block * 2, (uint32_t)kLoopBlockMax);
+        }
+        if (slots == 0) // no iteration at all: read the initial state back
+        {
+            HIP_TRY(c, hipMemcpyAsync(c->h_loop, c->loop_state, sizeof(LoopState),
+                                      hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
+        loop_results(c, *c->h_loop, T_out, iters_done, final_error);
+        c->timing.host_ms +=
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin)
+                .count();
+        return ICP_HIP_OK;
+    }
+
+    // The same loop driven from the host: every step's sums come back to the host, which runs the
+    // same scalar steps (loop_steps.hh) between the kernels.  This is the path of an all-reduce
+    // callback (icp_hip_set_allreduce), of the diagnostic counters and of the level-stack kernel.
+    // With a callback the order is the sharded one (one all-reduce of kIterSums doubles per
+    // iteration, the loop condition one slot late); both loops give the same bits.
+    int run_host_loop(icp_hip_ctx* c, const float mu_m[3], uint64_t max_iters, float threshold,
+                      float T_out[16], uint64_t* iters_done, float* final_error,
+                      icp_hip_progress_fn progress, void* user)
+    {
+        const auto t_begin = std::chrono::steady_clock::now();
         const uint32_t n = (uint32_t)c->n_local;
         const uint32_t g_st = stream_grid(n);
+        const uint32_t cap_iters = max_iters > 0xFFFFFFFEull ? 0xFFFFFFFEu : (uint32_t)max_iters;
+        const bool sharded = c->allreduce != nullptr;
         c->nn_trace.clear();
-        const uint32_t cap_iters = max_iters > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)max_iters;
-        uint32_t it_done = 0;
-        float error = std::numeric_limits<float>::infinity();
-        float T[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-        if (cap_iters > 0 && error > threshold)
+        LoopState st{};
+        int rc;
+        // first mean(p) (icp.cc:114); T = I, error = +inf (:101-104)
+        if ((rc = enqueue_first_sums(c)) != ICP_HIP_OK ||
+            (rc = sums_to_host(c, kApplyAt, kApplySums)) != ICP_HIP_OK ||
+            (rc = host_allreduce(c, kApplyAt, kApplySums)) != ICP_HIP_OK)
+            return rc;
+        loop_init_step(&st, c->h_sums + kApplyAt, mu_m, threshold, cap_iters, (double)c->n_total);
+
+        float nn_ms = 0.f, ap_ms = 0.f; // kernel times of the iteration whose error is pending
+        auto finished = [&](uint32_t it_before) {
+            if (st.it == it_before)
+                return;
+            c->timing.nn_ms += nn_ms;
+            c->timing.apply_ms += ap_ms;
+            c->timing.nn_launches += 1;
+            c->timing.queries += (double)c->n_total;
+            if (c->nn_trace.size() < 4096)
+                c->nn_trace.push_back(nn_ms);
+            if (progress)
+                progress(st.it, max_iters, st.error, user);
+        };
+        while (!st.done)
         {
-            // first mean(p) (icp.cc:114); later iterations get it from the apply pass
-            HIP_TRY(c, launch_sum_points(c->px.p, c->py.p, c->pz.p, n, g_st, c->partials.p,
-                                         c->stream));
-            HIP_TRY(c, launch_reduce_partials(c->partials.p, g_st, kApplySums, c->sums.p,
+            // y = tree.closest(p - mu_q); H = sum (p - mu_q) (x) y      icp.cc:115-117, :32-33
+            float ms = 0.f;
+            const bool idle = loop_nn_idle(&st);
+            if (!idle)
+            {
+                NnLaunch a = make_nn(c, st.mu_q, true, false, false, true);
+                if ((rc = enqueue_nn(c, a, kTailNone, c->ev0, c->ev1)) != ICP_HIP_OK)
+                    return rc;
+            }
+            const uint32_t it_before = st.it;
+            if (sharded)
+            {
+                // one all-reduce: this pass' sums + the apply pass' sums of the iteration before
+                if ((rc = sums_to_host(c, 0, kIterSums)) != ICP_HIP_OK ||
+                    (rc = host_allreduce(c, 0, kIterSums)) != ICP_HIP_OK)
+                    return rc;
+                if (!idle && n)
+                    ms = elapsed_ms(c);
+                loop_advance_step(&st, c->h_sums); // icp.cc:123,:110 then :119,:121
+                finished(it_before);
+            }
+            else
+            {
+                if ((rc = sums_to_host(c, 0, kCovSums)) != ICP_HIP_OK)
+                    return rc;
+                if (n)
+                    ms = elapsed_ms(c);
+                loop_solve_step(&st, c->h_sums); // icp.cc:119, :121
+            }
+            if (st.done)
+                break;
+            nn_ms = ms;
+            // p <- Tn p ; error ; next centroid                      icp.cc:122-123
+            if (n)
+            {
+                Mat34 M;
+                std::memcpy(M.m, st.Tn, sizeof M.m);
+                HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+                HIP_TRY(c, launch_apply_error(c->px.p, c->py.p, c->pz.p, c->yx.p, c->yy.p, c->yz.p,
+                                              M, st.mu_m, n, g_st, c->partials.p, nullptr,
                                               c->stream));
-            if (c->comm)
-            {
-                const int rc = g_rccl.AllReduce(c->sums.p, c->sums.p, (size_t)kApplySums,
-                                                Rccl::kDouble, Rccl::kSum, c->comm, c->stream);
-                if (rc != 0)
-                    return fail(c, ICP_HIP_ERR_COMM, "ncclAllReduce failed");
+                HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+                HIP_TRY(c, launch_reduce_partials(c->partials.p, g_st, kApplySums,
+                                                  c->sums.p + kApplyAt, c->stream));
             }
-            HIP_TRY(c, launch_loop_init(c->loop_state, c->sums.p, mu_m, threshold, cap_iters,
-                                        (double)c->n_total, c->stream));
-            uint32_t block = 1;
-            for (;;)
+            else
+                HIP_TRY(c, hipMemsetAsync(c->sums.p + kApplyAt, 0, sizeof(double) * kApplySums,
+                                          c->stream));
+            if (!sharded)
             {
-                uint32_t B = c->comm ? 1u : block;
-                if (B > cap_iters - it_done)
-                    B = cap_iters - it_done;
-                while (c->phase_timers && c->loop_events.size() < (size_t)4 * B)
-                {
-                    hipEvent_t ev = nullptr;
-                    HIP_TRY(c, hipEventCreate(&ev));
-                    c->loop_events.push_back(ev);
-                }
-                for (uint32_t s = 0; s < B; ++s)
-                {
-                    const int rc = enqueue_iteration(
-                        c, c->phase_timers ? c->loop_events.data() + 4 * s : nullptr);
-                    if (rc != ICP_HIP_OK)
-                        return rc;
-                }
-                HIP_TRY(c, hipMemcpyAsync(c->h_loop, c->loop_state, sizeof(LoopState),
-                                          hipMemcpyDeviceToHost, c->stream));
+                if ((rc = sums_to_host(c, kApplyAt, kApplySums)) != ICP_HIP_OK)
+                    return rc;
+                ap_ms = n ? elapsed_ms(c) : 0.f;
+                loop_finish_step(&st, c->h_sums + kApplyAt); // icp.cc:123, :110
+                finished(it_before);
+            }
+            else
+            {
                 HIP_TRY(c, hipStreamSynchronize(c->stream));
-                const LoopState& st = *c->h_loop;
-                for (uint32_t i = it_done; i < st.it; ++i)
-                {
-                    float nn_ms = 0.f, ap_ms = 0.f;
-                    if (c->phase_timers)
-                    {
-                        hipEvent_t* ev = c->loop_events.data() + 4 * (i - it_done);
-                        (void)hipEventElapsedTime(&nn_ms, ev[0], ev[1]);
-                        (void)hipEventElapsedTime(&ap_ms, ev[2], ev[3]);
-                    }
-                    c->timing.nn_ms += nn_ms;
-                    c->timing.apply_ms += ap_ms;
-                    c->timing.nn_launches += 1;
-                    c->timing.queries += (double)c->n_total;
-                    if (c->phase_timers && c->nn_trace.size() < 4096)
-                        c->nn_trace.push_back(nn_ms);
-                    if (progress)
-                        progress(i + 1, max_iters, st.errors[i % (uint32_t)kLoopBlockMax], user);
-                }
-                it_done = st.it;
-                if (st.done || it_done >= cap_iters)
-                    break;
-                block = block * 2 > (uint32_t)kLoopBlockMax ? (uint32_t)kLoopBlockMax : block * 2;
+                ap_ms = n ? elapsed_ms(c) : 0.f;
             }
-            const LoopState& st = *c->h_loop;
-            std::memcpy(T, st.T, sizeof T);
-            error = st.error;
-            c->timing.nodes_visited += st.work[0];
-            c->timing.points_scanned += st.work[1];
-            c->timing.stack_spills += st.work[2];
         }
-        std::memcpy(T_out, T, sizeof T);
-        if (iters_done)
-            *iters_done = it_done;
-        if (final_error)
-            *final_error = error;
+        loop_results(c, st, T_out, iters_done, final_error);
         c->timing.host_ms +=
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin)
                 .count();
@@ -1228,7 +1362,7 @@ extern "C"
         NnLaunch a = make_nn(c, mu_p, true, true, true, true);
         float ms = 0.f;
         {
-            int rc = nn_pass(c, a, false, &ms);
+            int rc = nn_pass(c, a, &ms);
             if (rc != ICP_HIP_OK)
                 return rc;
         }
@@ -1323,92 +1457,28 @@ extern "C"
         DeviceGuard g(c->device);
         // The loop stays on the device unless something needs the host between the kernels: the
         // all-reduce callback, the diagnostic counters, the level-stack kernel.  Both loops give
-        // the same bits (tests/test_gpu_icp_parity.py).
-        const bool can_device = c->tile_ready && !c->force_deep && !c->stats.p && !c->allreduce &&
-                                c->n_local > 0;
-        if (c->loop_mode != 1 && can_device)
+        // the same bits (tests/test_gpu_icp_parity.py).  With an RCCL communicator every rank
+        // must issue the same collectives, so the choice may not depend on anything a single rank
+        // sees (its environment, an empty shard): the loop is the device-resident one or the
+        // call fails.
+        const bool diagnostic = c->force_deep || c->stats.p || c->loop_mode == 1;
+        if (c->comm)
+        {
+            if (diagnostic || c->allreduce)
+                return fail(c, ICP_HIP_ERR_ARG,
+                            "icp_hip_run: with an RCCL communicator the loop runs on the device on "
+                            "every rank; ICP_HIP_NN_KERNEL=deep, ICP_HIP_TILE_STATS, "
+                            "ICP_HIP_LOOP=host and icp_hip_set_allreduce cannot be combined with it");
+            if (!c->tile_ready && c->n_local > 0)
+                return fail(c, ICP_HIP_ERR_ARG, "icp_hip_run: the NN kernel is not set up");
             return run_device_loop(c, mu_m, max_iters, threshold, T_out, iters_done, final_error,
                                    progress, user);
-        const auto t_begin = std::chrono::steady_clock::now();
-        const uint32_t n = (uint32_t)c->n_local;
-        const uint32_t g_st = stream_grid(n);
-        const double n_total = (double)c->n_total;
-
-        c->nn_trace.clear();
-        float T[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}; // icp.cc:101
-        float error = std::numeric_limits<float>::infinity();           // icp.cc:104
-        uint64_t it = 0;
-        int rc;
-
-        // first mean(p) (icp.cc:114); later iterations get it from the apply pass
-        float mu_p[3] = {0, 0, 0};
-        if (max_iters > 0 && error > threshold)
-        {
-            HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-            HIP_TRY(c, launch_sum_points(c->px.p, c->py.p, c->pz.p, n, g_st, c->partials.p,
-                                         c->stream));
-            HIP_TRY(c, launch_reduce_partials(c->partials.p, g_st, kApplySums, c->sums.p,
-                                              c->stream));
-            HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-            if ((rc = reduce_to_host(c, kApplySums)) != ICP_HIP_OK)
-                return rc;
-            c->timing.reduce_ms += elapsed_ms(c);
-            for (int k = 0; k < 3; ++k)
-                mu_p[k] = (float)(c->h_sums[1 + k] / n_total);
         }
-
-        for (; it < max_iters && error > threshold; ++it) // icp.cc:110
-        {
-            // y = tree.closest(p - mu_p); H = sum (p - mu_p) (x) y      icp.cc:115-117, :32-33
-            NnLaunch a = make_nn(c, mu_p, true, false, false, true);
-            float ms = 0.f;
-            if ((rc = nn_pass(c, a, true, &ms)) != ICP_HIP_OK)
-                return rc;
-            {
-                c->timing.nn_ms += ms;
-                c->timing.nn_launches += 1;
-                c->timing.nodes_visited += c->h_sums[9];
-                c->timing.points_scanned += c->h_sums[10];
-                c->timing.stack_spills += c->h_sums[11];
-                c->timing.queries += (double)c->n_total;
-                if (c->nn_trace.size() < 4096)
-                    c->nn_trace.push_back(ms);
-            }
-
-            float H[9], Tn[16], Tt[16];
-            for (int k = 0; k < 9; ++k)
-                H[k] = (float)c->h_sums[k];
-            icp_host::alignment_from_covariance(H, mu_p, mu_m, Tn); // icp.cc:119
-            icp_host::matmul4(Tn, T, Tt);                           // icp.cc:121
-            std::memcpy(T, Tt, sizeof T);
-
-            // p <- Tn p ; error ; next centroid                      icp.cc:122-123
-            Mat34 M;
-            std::memcpy(M.m, Tn, sizeof M.m);
-            HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-            HIP_TRY(c, launch_apply_error(c->px.p, c->py.p, c->pz.p, c->yx.p, c->yy.p, c->yz.p, M,
-                                          mu_m, n, g_st, c->partials.p, nullptr, c->stream));
-            HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-            HIP_TRY(c, launch_reduce_partials(c->partials.p, g_st, kApplySums, c->sums.p,
-                                              c->stream));
-            if ((rc = reduce_to_host(c, kApplySums)) != ICP_HIP_OK)
-                return rc;
-            c->timing.apply_ms += elapsed_ms(c);
-            error = (float)c->h_sums[0];
-            for (int k = 0; k < 3; ++k)
-                mu_p[k] = (float)(c->h_sums[1 + k] / n_total);
-            if (progress)
-                progress(it + 1, max_iters, error, user);
-        }
-        std::memcpy(T_out, T, sizeof T);
-        if (iters_done)
-            *iters_done = it;
-        if (final_error)
-            *final_error = error;
-        c->timing.host_ms +=
-            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin)
-                .count();
-        return ICP_HIP_OK;
+        if (!diagnostic && !c->allreduce && c->tile_ready && c->n_local > 0)
+            return run_device_loop(c, mu_m, max_iters, threshold, T_out, iters_done, final_error,
+                                   progress, user);
+        return run_host_loop(c, mu_m, max_iters, threshold, T_out, iters_done, final_error,
+                             progress, user);
     }
 
     int icp_hip_get_points(icp_hip_ctx* c, float* xyz_aos)

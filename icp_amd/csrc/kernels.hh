@@ -41,6 +41,11 @@ namespace icp_dev
                                   // (the reference traversal's deterministic work counters);
                                   // [11] stack entries nn_tile_kernel spilled from LDS to HBM
     constexpr int kApplySums = 4; // error, sum x', sum y', sum z'
+    // The sums of one iteration as the loop keeps (and all-reduces) them, 16 doubles:
+    // [0..11] the NN pass' kCovSums, [12..15] the kApplySums of the apply pass before it (the
+    // centroid sums of the initial cloud for the first iteration).
+    constexpr int kIterSums = kCovSums + kApplySums;
+    constexpr int kApplyAt = kCovSums;
     constexpr uint32_t kNnMaxBlocks = 256 * 8;
     constexpr uint32_t kSlotSlack = 256; // a staged bucket window may read this far past a bucket
     constexpr uint32_t kStreamMaxBlocks = 256 * 8;
@@ -54,14 +59,17 @@ namespace icp_dev
     {
         float T[16];     // accumulated transform (icp.cc:121)
         float Tn[12];    // rows 0..2 of this iteration's transform, read by apply_error_kernel
-        float mu_p[3];   // centroid of the moved cloud, read by the NN kernel (icp.cc:114)
+        float mu_p[3];   // centroid of the cloud to move (icp.cc:114), used by the solve (:57)
+        float mu_q[3];   // what the NN kernel subtracts from p (:115): mu_p in the first iteration,
+                         // mu_m afterwards (t = mu_m - r mu_p puts the moved centroid on mu_m up to
+                         // fp32 rounding, so the next pass needs no sum of the moved cloud first)
         float mu_m[3];
         float error;     // icp.cc:123
         float threshold;
-        uint32_t it;     // iterations completed
+        uint32_t it;     // iterations completed (error known, loop condition evaluated)
+        uint32_t started; // iterations solved and applied; started - it is 0 or 1
         uint32_t max_iters;
         uint32_t done;
-        uint32_t pad_;
         double n_total;
         double work[3];  // reference-traversal counters summed over the iterations (sums 9..11)
         float errors[kLoopBlockMax]; // error after iteration i at [i % kLoopBlockMax]
@@ -81,7 +89,7 @@ namespace icp_dev
         const uint32_t* perm; // may be null: row_out/dist_out are written at perm[i] (input order)
         double* partials;    // [grid][kCovSums] or null
         uint32_t grid;
-        const LoopState* loop; // device-resident loop: mu comes from loop->mu_p, no-op once done
+        const LoopState* loop; // device-resident loop: mu comes from loop->mu_q, no-op once done
     };
 
     int nn_max_depth_supported();
@@ -120,8 +128,9 @@ namespace icp_dev
     // loop.hip: single-thread steps of the device-resident loop
     hipError_t launch_loop_init(LoopState* st, const double* sums, const float mu_m[3],
                                 float threshold, uint32_t max_iters, double n_total, hipStream_t s);
-    hipError_t launch_loop_solve(LoopState* st, const double* sums, hipStream_t s);
-    hipError_t launch_loop_finish(LoopState* st, const double* sums, hipStream_t s);
+    // sums = the kIterSums doubles of one iteration (all-reduced): finish the iteration whose apply
+    // pass is pending, if any, then solve the next one unless the loop is over
+    hipError_t launch_loop_advance(LoopState* st, const double* sums, hipStream_t s);
     hipError_t launch_sum_points(const float* px, const float* py, const float* pz, uint32_t n,
                                  uint32_t grid, double* partials, hipStream_t s);
     // `loop` + `tail`: the device-resident loop's scalar step on these sums, run by the same

@@ -8,6 +8,10 @@
 //                subtract / to_transformation kernels (:35-62)
 //   loop_finish  error (:123) and the next centroid from the apply pass' sums; the loop condition
 //                (:110) -> `done`
+//   loop_advance finish + solve on one set of sums: the step of a sharded run, whose single
+//                all-reduce per iteration carries both
+// The steps themselves are in loop_steps.hh (host and device: the host-driven loop runs the same
+// source).  loop_solve / loop_finish run as the tail of reduce_partials_kernel (kernels.hip).
 //
 // One thread each: nine floats in, sixteen out.  No MFMA: nothing here is a dense contraction.
 
@@ -27,37 +31,14 @@ namespace icp_dev
         {
             if (threadIdx.x != 0 || blockIdx.x != 0)
                 return;
-            for (int i = 0; i < 16; ++i)
-                st->T[i] = (i % 5 == 0) ? 1.0f : 0.0f;
-            for (int i = 0; i < 12; ++i)
-                st->Tn[i] = (i % 5 == 0) ? 1.0f : 0.0f;
-            st->mu_m[0] = mx;
-            st->mu_m[1] = my;
-            st->mu_m[2] = mz;
-            for (int k = 0; k < 3; ++k)
-                st->mu_p[k] = (float)(sums[1 + k] / n_total);
-            const float inf = __int_as_float(0x7f800000);
-            st->error = inf;
-            st->threshold = threshold;
-            st->it = 0;
-            st->max_iters = max_iters;
-            st->done = (max_iters > 0u && inf > threshold) ? 0u : 1u;
-            st->n_total = n_total;
-            st->work[0] = st->work[1] = st->work[2] = 0.0;
-            for (int i = 0; i < kLoopBlockMax; ++i)
-                st->errors[i] = 0.0f;
+            const float mu_m[3] = {mx, my, mz};
+            loop_init_step(st, sums, mu_m, threshold, max_iters, n_total);
         }
 
-        __global__ void loop_solve_kernel(LoopState* st, const double* sums)
+        __global__ void loop_advance_kernel(LoopState* st, const double* sums)
         {
             if (threadIdx.x == 0 && blockIdx.x == 0)
-                loop_solve_step(st, sums);
-        }
-
-        __global__ void loop_finish_kernel(LoopState* st, const double* sums)
-        {
-            if (threadIdx.x == 0 && blockIdx.x == 0)
-                loop_finish_step(st, sums);
+                loop_advance_step(st, sums);
         }
     } // namespace
 
@@ -68,14 +49,9 @@ namespace icp_dev
                            mu_m[2], threshold, max_iters, n_total);
         return hipGetLastError();
     }
-    hipError_t launch_loop_solve(LoopState* st, const double* sums, hipStream_t s)
+    hipError_t launch_loop_advance(LoopState* st, const double* sums, hipStream_t s)
     {
-        hipLaunchKernelGGL(loop_solve_kernel, dim3(1), dim3(64), 0, s, st, sums);
-        return hipGetLastError();
-    }
-    hipError_t launch_loop_finish(LoopState* st, const double* sums, hipStream_t s)
-    {
-        hipLaunchKernelGGL(loop_finish_kernel, dim3(1), dim3(64), 0, s, st, sums);
+        hipLaunchKernelGGL(loop_advance_kernel, dim3(1), dim3(64), 0, s, st, sums);
         return hipGetLastError();
     }
 } // namespace icp_dev

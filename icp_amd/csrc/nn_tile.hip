@@ -365,11 +365,12 @@ namespace icp_dev
             {
                 // device-resident loop (loop.hip): the centroid comes from the previous
                 // iteration's sums; an iteration enqueued past the end of the loop does nothing
-                if (loop->done)
+                // (or has started its last iteration and only waits for that one's error)
+                if (loop->done || loop->started >= loop->max_iters)
                     return;
-                mux = loop->mu_p[0];
-                muy = loop->mu_p[1];
-                muz = loop->mu_p[2];
+                mux = loop->mu_q[0];
+                muy = loop->mu_q[1];
+                muz = loop->mu_q[2];
             }
             // wave-level event counts of the diagnostic build (ICP_HIP_TILE_STATS=1)
             uint32_t st_node = 0, st_tile = 0, st_tile_g = 0, st_tile_len = 0, st_coop = 0,

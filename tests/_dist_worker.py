@@ -28,33 +28,67 @@ def main():
     result = {"rank": rank, "shard": [b, e]}
 
     if mode == "cpu":
-        # The sharded decomposition of one iteration with the oracle standing in for the kernels:
-        # per-shard fp64 partial sums, summed by the SAME callback object the C ABI calls.
+        # The sharded decomposition of the loop with the oracle standing in for the kernels, in
+        # the order the library uses: ONE all-reduce of 16 doubles per iteration -- [0..8] the
+        # covariance sums and [9..11] the work counters of this iteration's NN pass, [12..15] the
+        # error and the moved-cloud sums of the apply pass before it -- summed by the SAME
+        # callback type the C ABI calls (icp_hip_set_allreduce).
         from oracle import Oracle
         orc = Oracle()
         mu_m = orc.mean(m)
         mc = orc.subtract(m, mu_m)
         tree = orc.tree_build(cap, mc)
-        sums = np.zeros(4)
-        sums[1:] = p[b:e].astype(np.float64).sum(0)
-        cb = capi.ALLREDUCE_FN(lambda ptr, cnt, _u: (allreduce(np.ctypeslib.as_array(ptr, shape=(cnt,))), 0)[1])
-        assert cb(sums.ctypes.data_as(C.POINTER(C.c_double)), 4, None) == 0
-        mu_p = (sums[1:] / n).astype(np.float32)
-        q = orc.subtract(p[b:e], mu_p)
-        nn = orc.tree_closest(tree, q, counters=True)
-        cov = np.zeros(11)
-        cov[:9] = (q[:, :, None] * nn["xyz"][:, None, :]).astype(np.float32).astype(np.float64).sum(0).reshape(9)
-        cov[9], cov[10] = nn["n_int"].sum(), nn["n_pts"].sum()
-        assert cb(cov.ctypes.data_as(C.POINTER(C.c_double)), 11, None) == 0
-        T = capi.alignment_host(cov[:9].astype(np.float32), mu_p, mu_m)
-        moved = orc.apply_alignment(p[b:e], T)
-        d = (nn["xyz"] + mu_m - moved).astype(np.float32)
-        err = np.zeros(4)
-        err[0] = ((d * d).astype(np.float32)).astype(np.float64).sum()
-        assert cb(err.ctypes.data_as(C.POINTER(C.c_double)), 4, None) == 0
-        result.update(mu_p=[float(v) for v in mu_p], cov=[float(v) for v in cov],
-                      T=[float(v) for v in T.reshape(-1)], err=float(err[0]),
-                      rows=nn["row"].tolist())
+        calls = []
+
+        def reduce(v):
+            calls.append(len(v))
+            allreduce(v)
+        cb = capi.ALLREDUCE_FN(lambda ptr, cnt, _u: (reduce(np.ctypeslib.as_array(ptr, shape=(cnt,))), 0)[1])
+        mine = p[b:e].copy()
+        first = np.zeros(4)
+        first[1:] = mine.astype(np.float64).sum(0)
+        assert cb(first.ctypes.data_as(C.POINTER(C.c_double)), 4, None) == 0
+        mu_p = (first[1:] / n).astype(np.float32)
+        mu_q = mu_p.copy()
+        carry = np.zeros(4)
+        T_tot = np.eye(4, dtype=np.float32)
+        errors, rows, covs = [], [], []
+        for it in range(3):
+            q = orc.subtract(mine, mu_q)
+            nn = orc.tree_closest(tree, q, counters=True)
+            sums = np.zeros(16)
+            sums[:9] = (q[:, :, None] * nn["xyz"][:, None, :]).astype(np.float32).astype(np.float64).sum(0).reshape(9)
+            sums[9], sums[10] = nn["n_int"].sum(), nn["n_pts"].sum()
+            sums[12:] = carry
+            assert cb(sums.ctypes.data_as(C.POINTER(C.c_double)), 16, None) == 0
+            if it > 0:  # the apply pass of the iteration before: its error and the next centroid
+                errors.append(float(np.float32(sums[12])))
+                mu_p = (sums[13:] / n).astype(np.float32)
+            Tn = capi.alignment_host(sums[:9].astype(np.float32), mu_p, mu_m)
+            T_tot = orc.matmul4(Tn, T_tot)
+            mu_q = mu_m.copy()
+            mine = orc.apply_alignment(mine, Tn)
+            d = (nn["xyz"] + mu_m - mine).astype(np.float32)
+            carry = np.zeros(4)
+            carry[0] = ((d * d).astype(np.float32)).astype(np.float64).sum()
+            carry[1:] = mine.astype(np.float64).sum(0)
+            rows.append(nn["row"].tolist())
+            covs.append([float(v) for v in sums[:12]])
+        result.update(calls=calls, covs=covs, errors=errors, rows=rows,
+                      T=[float(v) for v in T_tot.reshape(-1)])
+    elif mode == "gpu_empty":
+        # rank 0 holds the whole cloud, rank 1 an empty shard (more ranks than points)
+        mu_m = capi.mean_host(m)
+        tree = capi.FlatTree(capi.center_host(m, mu_m), cap)
+        mine = p if rank == 0 else p[:0]
+        with capi.Context(0) as ctx:
+            ctx.set_tree(tree)
+            ctx.set_queries(mine, n_total=n)
+            ctx.set_allreduce(allreduce)
+            T, iters, err = ctx.run(mu_m, 50, 1e-5)
+            new_p = ctx.get_points()
+        result.update(T=[float(v) for v in T.reshape(-1)], iters=int(iters), err=float(err),
+                      new_p=new_p.tolist())
     else:
         # real GPU, both ranks on device 0, sums exchanged over gloo through the C-ABI callback
         mu_m = capi.mean_host(m)

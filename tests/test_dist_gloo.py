@@ -2,7 +2,7 @@
 
 Checks shard bounds, the all-reduce callback the C ABI calls (icp_hip_set_allreduce), and that
 the sharded decomposition of an iteration (per-shard fp64 partial sums -> all-reduce -> one SVD
-solve) reproduces the single-process iteration.  The oracle stands in for the kernels here; the
+solve) reproduces the single-process loop, and that bench.py starts its own ranks.  The oracle stands in for the kernels here; the
 same worker runs the real kernels in tests/test_gpu_sharded.py.
 """
 import json
@@ -57,30 +57,81 @@ def test_shard_bounds_partition():
             assert all(0 <= e - s for s, e in b)
 
 
-def test_two_rank_iteration_matches_single_process(tmp_path, oracle):
+def test_two_rank_iterations_match_single_process(tmp_path, oracle):
     res = run_workers("cpu", str(tmp_path / "out"))
     n, cap = 30011, 64
     m = synth.cloud(n, seed=21)
     p = synth.apply_fp32(m, synth.ground_truth(2.0))
     assert [r["shard"] for r in res] == [[0, 15006], [15006, 30011]]
+    # one set-up collective (the first centroid), then ONE of 16 doubles per iteration
+    assert res[0]["calls"] == res[1]["calls"] == [4, 16, 16, 16]
     # both ranks hold identical reduced values
-    for k in ("mu_p", "cov", "T", "err"):
+    for k in ("covs", "T", "errors"):
         assert res[0][k] == res[1][k], k
-    # single-process iteration with the same arithmetic
+    # single-process run of the same loop with the same arithmetic
     mu_m = oracle.mean(m)
-    mc = oracle.subtract(m, mu_m)
-    tree = oracle.tree_build(cap, mc)
+    tree = oracle.tree_build(cap, oracle.subtract(m, mu_m))
     mu_p = (p.astype(np.float64).sum(0) / n).astype(np.float32)
-    assert np.allclose(res[0]["mu_p"], mu_p, rtol=0, atol=1e-7)
-    q = oracle.subtract(p, np.array(res[0]["mu_p"], np.float32))
-    nn = oracle.tree_closest(tree, q, counters=True)
-    rows = np.concatenate([np.array(r["rows"], np.uint32) for r in res])
-    assert (rows == nn["row"]).all()  # NN answers do not depend on the sharding
-    cov = (q[:, :, None] * nn["xyz"][:, None, :]).astype(np.float32).astype(np.float64).sum(0).reshape(9)
-    assert np.allclose(res[0]["cov"][:9], cov, rtol=1e-12, atol=1e-9)
-    assert res[0]["cov"][9] == nn["n_int"].sum() and res[0]["cov"][10] == nn["n_pts"].sum()
-    T = capi.alignment_host(np.array(res[0]["cov"][:9], np.float32), np.array(res[0]["mu_p"], np.float32), mu_m)
-    assert (np.array(res[0]["T"], np.float32).reshape(4, 4) == T).all()
-    # and the reference-order fp32 iteration agrees to summation accuracy
-    H32 = oracle.find_covariance(q, nn["xyz"])
-    assert np.allclose(res[0]["cov"][:9], H32, rtol=1e-4, atol=1e-3)
+    mu_q, cur, T_tot = mu_p.copy(), p.copy(), np.eye(4, dtype=np.float32)
+    for it in range(3):
+        q = oracle.subtract(cur, mu_q)
+        nn = oracle.tree_closest(tree, q, counters=True)
+        rows = np.concatenate([np.array(r["rows"][it], np.uint32) for r in res])
+        assert (rows == nn["row"]).all()  # NN answers do not depend on the sharding
+        cov = (q[:, :, None] * nn["xyz"][:, None, :]).astype(np.float32).astype(np.float64).sum(0).reshape(9)
+        got = np.array(res[0]["covs"][it])
+        assert np.allclose(got[:9], cov, rtol=1e-12, atol=1e-9)
+        assert got[9] == nn["n_int"].sum() and got[10] == nn["n_pts"].sum()
+        Tn = capi.alignment_host(got[:9].astype(np.float32), mu_p, mu_m)
+        T_tot = oracle.matmul4(Tn, T_tot)
+        cur = oracle.apply_alignment(cur, Tn)
+        mu_q = mu_m.copy()
+        if it < 2:
+            d = (nn["xyz"] + mu_m - cur).astype(np.float32)
+            err = np.float32(((d * d).astype(np.float32)).astype(np.float64).sum())
+            assert np.isclose(res[0]["errors"][it], err, rtol=1e-6)
+            mu_p = (cur.astype(np.float64).sum(0) / n).astype(np.float32)
+            # the identity the loop rests on: the moved centroid sits on mu_m
+            assert np.abs(mu_p - mu_m).max() <= 2e-7
+        # the reference-order fp32 covariance agrees to summation accuracy
+        assert np.allclose(got[:9], oracle.find_covariance(q, nn["xyz"]), rtol=1e-4, atol=1e-3)
+    assert (np.array(res[0]["T"], np.float32).reshape(4, 4) == T_tot).all()
+    # the same loop converges like libcpu's (error trajectory of oracle.icp within fp32 noise)
+    cpu = oracle.icp(m, p, 50, 1e-5, cap)
+    assert np.allclose(res[0]["errors"], cpu["errors"][:2], rtol=1e-3)
+
+
+def test_bench_launcher_starts_its_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must run TWO ranks (the launch path,
+    rehearsed without a GPU: rendezvous over gloo, shard split, a sum over the ranks)."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse",
+                        "--workload", "1M"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2
+    assert line["queries_total"] == 1_000_000 and line["config"]["queries_per_gpu"] == 500_000
+    assert line["config"]["parallelism"] == "query-shard x2"
+    # one rank, unchanged
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--rehearse",
+                        "--workload", "1M"], env=env, capture_output=True, text=True, timeout=300)
+    line = json.loads(r.stdout.splitlines()[-1])
+    assert r.returncode == 0 and line["n_gpus"] == 1
+    # a launcher that started a different number of ranks is an error, not a silent n_gpus: 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--rehearse"],
+                       env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_bench_launcher_reports_a_failing_rank():
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    # no GPU here: every rank fails loudly, and so does the launcher
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload",
+                        "1M", "--steps", "1", "--warmup", "0"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    if r.returncode == 0:
+        pytest.skip("a GPU node with >= 2 devices: the real launch ran")
+    assert "exited with status" in r.stderr or "needs GPU" in r.stderr

@@ -26,10 +26,47 @@ def test_two_contexts_match_one(tmp_path):
     assert new_p.shape == new_p1.shape and np.abs(new_p - new_p1).max() <= 1e-6
 
 
+def test_empty_shard_takes_part_in_every_collective(tmp_path):
+    """More ranks than points: a rank with an empty shard issues the same all-reduces and ends
+    with the same transform."""
+    import icp_amd
+    from icp_amd import synth
+    n, cap = 30011, 64
+    m = synth.cloud(n, seed=21)
+    p = synth.apply_fp32(m, synth.ground_truth(2.0))
+    T1, new_p1, info = icp_amd.icp(m, p, 50, 1e-5, cap, return_info=True)
+    res = run_workers("gpu_empty", str(tmp_path / "out"))
+    assert res[0]["iters"] == res[1]["iters"] == info["iterations"]
+    assert res[0]["T"] == res[1]["T"]
+    assert (np.array(res[0]["T"], np.float32).reshape(4, 4).view(np.uint32) == T1.view(np.uint32)).all()
+    assert len(res[1]["new_p"]) == 0
+    assert (np.array(res[0]["new_p"], np.float32).view(np.uint32) == new_p1.view(np.uint32)).all()
+
+
+def test_rccl_communicator_rejects_per_rank_loop_overrides(monkeypatch):
+    """With a communicator the loop choice must not depend on one rank's environment."""
+    from icp_amd import capi, synth
+    m = synth.cloud(5000, seed=3)
+    mu_m = capi.mean_host(m)
+    tree = capi.FlatTree(capi.center_host(m, mu_m), 32)
+    monkeypatch.setenv("ICP_HIP_LOOP", "host")
+    with capi.Context() as ctx:
+        ctx.set_tree(tree)
+        ctx.comm_init_rank(1, 0, capi.Context.comm_unique_id())
+        ctx.set_queries(m)
+        with pytest.raises(capi.IcpHipError) as e:
+            ctx.run(mu_m, 5, 1e-5)
+        assert e.value.status == 1 and "communicator" in str(e.value)
+    tree.close()
+
+
 def test_rccl_communicator_single_rank():
     """The RCCL leg (icp_hip_comm_init_rank: dlopen of librccl, ncclAllReduce of the sums on the
     context's stream) with a communicator of one rank: same bits as the run without it.  More
-    ranks need more GPUs than the test box has; bench.py --gpus N takes this same path."""
+    ranks need more GPUs than the test box has; bench.py --gpus N takes this same path.  With a
+    communicator the loop runs in the sharded order (one all-reduce of 16 doubles per iteration,
+    the loop condition one slot late, a speculative NN pass at the end): same bits again, also when
+    the iteration cap ends the loop and for every block position of the end."""
     from icp_amd import capi, synth
     n, cap = 50_000, 64
     m = synth.cloud(n, seed=31)
@@ -49,3 +86,26 @@ def test_rccl_communicator_single_rank():
     assert out[0][1] == out[1][1] and out[0][2] == out[1][2]
     assert (out[0][0].view(np.uint32) == out[1][0].view(np.uint32)).all()
     assert (out[0][3].view(np.uint32) == out[1][3].view(np.uint32)).all()
+    # the loop ended by the cap, at every position inside the blocks of 1, 2, 4, 8 slots
+    tree = capi.FlatTree(capi.center_host(m, mu_m), cap)
+    with capi.Context() as plain, capi.Context() as sharded:
+        plain.set_tree(tree)
+        sharded.set_tree(tree)
+        sharded.comm_init_rank(1, 0, capi.Context.comm_unique_id())
+        for cap_iters in (0, 1, 2, 3, 4, 7, 8, 15, 16):
+            res = []
+            for ctx in (plain, sharded):
+                ctx.set_queries(p)
+                errs = []
+                T, iters, err = ctx.run(mu_m, cap_iters, 0.0, progress=lambda i, mx, e: errs.append((i, e)))
+                res.append((T.copy(), iters, err, errs, ctx.get_points(), ctx.timing()))
+            assert res[0][1] == res[1][1] == cap_iters
+            assert res[0][3] == res[1][3] and [i for i, _ in res[0][3]] == list(range(1, cap_iters + 1))
+            assert (res[0][0].view(np.uint32) == res[1][0].view(np.uint32)).all()
+            assert (res[0][4].view(np.uint32) == res[1][4].view(np.uint32)).all()
+            for k in ("nn_launches", "queries", "nodes_visited", "points_scanned"):
+                assert res[0][5][k] == res[1][5][k], k
+            # what the loop rests on: the centroid of the moved cloud sits on mu_m
+            if cap_iters:
+                assert np.abs(res[0][4].mean(0, dtype=np.float64) - mu_m).max() <= 3e-7
+    tree.close()
