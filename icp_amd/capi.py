@@ -22,7 +22,7 @@ EXPORTS = [
     "icp_hip_center_host", "icp_hip_alignment_host", "icp_hip_create", "icp_hip_destroy", "icp_hip_last_error",
     "icp_hip_last_global_error", "icp_hip_set_tree", "icp_hip_build_tree", "icp_hip_get_tree",
     "icp_hip_get_tree_info", "icp_hip_read_csv", "icp_hip_read_f32", "icp_hip_free_points",
-    "icp_hip_set_queries", "icp_hip_nn",
+    "icp_hip_set_queries", "icp_hip_nn", "icp_hip_nn_noalloc",
     "icp_hip_set_allreduce", "icp_hip_comm_unique_id", "icp_hip_comm_init_rank", "icp_hip_run",
     "icp_hip_get_points", "icp_hip_get_timing", "icp_hip_get_nn_trace", "icp_hip_icp",
     "icp_hip_set_phase_timers",
@@ -102,6 +102,7 @@ def load() -> C.CDLL:
     L.icp_hip_get_tree_info.argtypes = [vp, treep]
     L.icp_hip_set_queries.argtypes = [vp, vp, u64, u64]
     L.icp_hip_nn.argtypes = [vp, vp, vp, vp, vp, C.POINTER(C.c_float)]
+    L.icp_hip_nn_noalloc.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.icp_hip_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp]
     L.icp_hip_comm_unique_id.argtypes = [vp, C.c_size_t]
     L.icp_hip_comm_init_rank.argtypes = [vp, C.c_int, C.c_int, vp, C.c_size_t]
@@ -297,6 +298,17 @@ class Context:
                                   dist.ctypes.data if dist is not None else None, C.byref(ms)),
                self._h)
         return dict(row=row, xyz=xyz, dist=dist, kernel_ms=ms.value)
+
+    def nn_noalloc(self, d_px: int, d_py: int, d_pz: int, n: int, mu_p, d_row: int = 0,
+                   d_dist: int = 0, d_yx: int = 0, d_yy: int = 0, d_yz: int = 0, d_sums: int = 0,
+                   stream: int = 0):
+        """icp_hip_nn_noalloc: every d_* is a DEVICE address (int, 0 = NULL) of a buffer the caller
+        owns; enqueued on `stream` (a hipStream_t as int), nothing is waited for or allocated."""
+        mu = np.ascontiguousarray(mu_p, np.float32)
+        _check(self._L.icp_hip_nn_noalloc(self._h, d_px, d_py, d_pz, int(n), mu.ctypes.data,
+                                          d_row or None, d_dist or None, d_yx or None,
+                                          d_yy or None, d_yz or None, d_sums or None,
+                                          stream or None), self._h)
 
     def set_allreduce(self, fn):
         """fn(np.ndarray[float64]) sums the array in place over all shards."""

@@ -291,30 +291,12 @@ namespace
         c->tile_ready = false;
         if (!c->has_tree || !c->has_queries || c->n_local == 0)
             return ICP_HIP_OK;
-        // queries per batch: 64 (one per lane) when that fills every resident wave slot; a
-        // smaller shard is cut into narrower batches (32/16/8/4 queries per wave) so that all
-        // SIMDs get work and each wave's serial chain of bucket scans is shorter
-        uint32_t bq = 64;
-        {
-            const char* env = std::getenv("ICP_HIP_BATCH_QUERIES");
-            const int forced = env ? std::atoi(env) : 0;
-            if (forced == 64 || forced == 32 || forced == 16 || forced == 8 || forced == 4 || forced == 2)
-                bq = (uint32_t)forced;
-            else
-                while (bq > 4 && (c->n_local + bq - 1) / bq < (uint64_t)c->tile_blocks * 4)
-                    bq >>= 1;
-        }
-        c->batch_queries = bq;
-        const uint64_t batches = (c->n_local + bq - 1) / bq;
-        // every workgroup resident; at least one batch per wave
-        uint64_t g = (batches + 3) / 4;
-        if (g > c->tile_blocks)
-            g = c->tile_blocks;
-        c->tile_grid_blocks = (uint32_t)(g < 1 ? 1 : g);
-        // chunks: ~8 per wave for load balance, at most 8 batches each
-        uint64_t cb = batches / ((uint64_t)c->tile_grid_blocks * 4 * 8);
-        c->chunk_batches = (uint32_t)(cb < 1 ? 1 : (cb > 8 ? 8 : cb));
-        c->n_chunks = (uint32_t)((batches + c->chunk_batches - 1) / c->chunk_batches);
+        const char* env = std::getenv("ICP_HIP_BATCH_QUERIES");
+        const TilePlan plan = plan_tile(c->n_local, c->tile_blocks, env ? (uint32_t)std::atoi(env) : 0u);
+        c->batch_queries = plan.batch_queries;
+        c->tile_grid_blocks = plan.grid_blocks;
+        c->chunk_batches = plan.chunk_batches;
+        c->n_chunks = plan.n_chunks;
         const uint32_t k = nn_tile_stack_entries();
         c->spill_levels = c->height > k ? c->height - k : 0;
         HIP_TRY(c, c->queue.alloc(kQueueWords));
@@ -1030,6 +1012,9 @@ extern "C"
             if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount,
                                            device_id)) != hipSuccess)
                 return bail(e, "hipDeviceGetAttribute");
+            // the static scratch array of icp_hip_nn_noalloc: its address on this device
+            if ((e = nn_noalloc_setup(device_id)) != hipSuccess)
+                return bail(e, "hipGetSymbolAddress(scratch)");
             uint64_t blocks = (uint64_t)(per_cu > 0 ? per_cu : 1) * (uint64_t)(cus > 0 ? cus : 1);
             if (blocks > kNnMaxBlocks)
                 blocks = kNnMaxBlocks;
@@ -1390,6 +1375,50 @@ extern "C"
         if (xyz_out)
             HIP_TRY(c, hipMemcpy(xyz_out, c->aos.p, 3ull * n * sizeof(float),
                                  hipMemcpyDeviceToHost));
+        return ICP_HIP_OK;
+    }
+
+    int icp_hip_nn_noalloc(icp_hip_ctx* c, const float* d_px, const float* d_py, const float* d_pz,
+                           uint32_t n, const float mu_p[3], uint32_t* d_row_out, float* d_dist_out,
+                           float* d_yx, float* d_yy, float* d_yz, double* d_sums_out, void* stream)
+    {
+        if (!c || !mu_p || !d_px || !d_py || !d_pz)
+            return fail(c, ICP_HIP_ERR_ARG, "icp_hip_nn_noalloc: NULL argument");
+        if (!c->has_tree)
+            return fail(c, ICP_HIP_ERR_ARG, "icp_hip_nn_noalloc: the context has no tree");
+        if ((d_yx || d_yy || d_yz) && !(d_yx && d_yy && d_yz))
+            return fail(c, ICP_HIP_ERR_ARG, "icp_hip_nn_noalloc: d_yx, d_yy, d_yz go together");
+        if (n == 0)
+            return ICP_HIP_OK;
+        if (n > kNoAllocMaxQueries)
+            return fail(c, ICP_HIP_ERR_ARG,
+                        "icp_hip_nn_noalloc: " + std::to_string(n) + " queries exceed the " +
+                            std::to_string(kNoAllocMaxQueries) +
+                            " the static scratch array is sized for; use icp_hip_nn");
+        if (c->height > nn_tile_stack_entries() + kNoAllocSpillLevels)
+            return fail(c, ICP_HIP_ERR_DEPTH,
+                        "icp_hip_nn_noalloc: tree height " + std::to_string(c->height) +
+                            " exceeds the static overflow stack (" +
+                            std::to_string(nn_tile_stack_entries() + kNoAllocSpillLevels) +
+                            " levels); use icp_hip_nn");
+        DeviceGuard g(c->device);
+        NnLaunch a{};
+        a.tree = c->tree;
+        a.height = c->height;
+        a.max_leaf_count = c->max_leaf;
+        a.px = d_px;
+        a.py = d_py;
+        a.pz = d_pz;
+        a.mu[0] = mu_p[0];
+        a.mu[1] = mu_p[1];
+        a.mu[2] = mu_p[2];
+        a.n = n;
+        a.yx = d_yx;
+        a.yy = d_yy;
+        a.yz = d_yz;
+        a.row_out = d_row_out;
+        a.dist_out = d_dist_out;
+        HIP_TRY(c, launch_nn_noalloc(c->device, a, d_sums_out, c->tile_cut, (hipStream_t)stream));
         return ICP_HIP_OK;
     }
 

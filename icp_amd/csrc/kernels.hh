@@ -115,6 +115,32 @@ namespace icp_dev
         uint32_t cut; // leave the node phase when waiting lanes >= cut/16 x stepping lanes (0: never)
     };
     hipError_t launch_nn_tile(const NnLaunch& a, const TileLaunch& q, hipStream_t s);
+    // How a shard of n queries is laid on a grid of at most max_blocks resident workgroups.
+    struct TilePlan
+    {
+        uint32_t batch_queries, grid_blocks, chunk_batches, n_chunks;
+    };
+    TilePlan plan_tile(uint64_t n, uint32_t max_blocks, uint32_t forced_batch_queries);
+
+    // ---- the pass that allocates nothing (icp_hip_nn_noalloc) ----
+    // Its work queue, per-chunk sums, partial rows and overflow stack live in a file-scope
+    // __device__ array of nn_tile.hip (kNoAllocScratchBytes, held by every GPU the library runs
+    // on); the limits below are what that array is sized for.
+    constexpr uint32_t kNoAllocMaxQueries = 1u << 20; // queries per call
+    constexpr uint32_t kNoAllocMaxBlocks = 256;       // grid: one workgroup per CU
+    constexpr uint32_t kNoAllocMaxChunks = 16384;     // plan_tile(n <= 2^20, 256 blocks) stays below
+    constexpr uint32_t kNoAllocSpillLevels = 28;      // tree height <= 28 + the on-chip entries
+    constexpr size_t kNoAllocScratchBytes =
+        4096                                                        // queue heads
+        + (size_t)kNoAllocMaxChunks * kCovSums * 8                    // per-chunk sums
+        + (size_t)1024 * kCovSums * 8                               // partial rows
+        + (size_t)kNoAllocSpillLevels * kNoAllocMaxBlocks * 256 * 8; // overflow stack
+    // once per device, with that device current: resolves the array's device address
+    hipError_t nn_noalloc_setup(int device);
+    // a: tree, inputs and outputs (a.grid, a.partials ignored); sums_out: kCovSums doubles in
+    // device memory or null.  Returns hipErrorInvalidValue beyond the limits above.
+    hipError_t launch_nn_noalloc(int device, const NnLaunch& a, double* sums_out, uint32_t cut,
+                                 hipStream_t s);
     hipError_t nn_tile_blocks_per_cu(int* out);
     uint32_t nn_tile_stack_entries();
     // out[b][k] = sum of rows [b*rows_per_block, ...) of rows[n_rows][K], fixed order; K <= 16

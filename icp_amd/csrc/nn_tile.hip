@@ -35,6 +35,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "device_common.hh"
 #include "kernels.hh"
 
@@ -814,6 +816,121 @@ namespace icp_dev
     }
 
     uint32_t nn_tile_stack_entries() { return kStackK; }
+
+    TilePlan plan_tile(uint64_t n, uint32_t max_blocks, uint32_t forced_bq)
+    {
+        // queries per batch: 64 (one per lane) when that fills every resident wave slot; a
+        // smaller shard is cut into narrower batches (32/16/8/4 queries per wave) so that all
+        // SIMDs get work and each wave's serial chain of bucket scans is shorter
+        TilePlan p{};
+        uint32_t bq = 64;
+        if (forced_bq == 64 || forced_bq == 32 || forced_bq == 16 || forced_bq == 8 ||
+            forced_bq == 4 || forced_bq == 2)
+            bq = forced_bq;
+        else
+            while (bq > 4 && (n + bq - 1) / bq < (uint64_t)max_blocks * 4)
+                bq >>= 1;
+        p.batch_queries = bq;
+        const uint64_t batches = (n + bq - 1) / bq;
+        // every workgroup resident; at least one batch per wave
+        uint64_t g = (batches + 3) / 4;
+        if (g > max_blocks)
+            g = max_blocks;
+        p.grid_blocks = (uint32_t)(g < 1 ? 1 : g);
+        // chunks: ~8 per wave for load balance, at most 8 batches each
+        const uint64_t cb = batches / ((uint64_t)p.grid_blocks * 4 * 8);
+        p.chunk_batches = (uint32_t)(cb < 1 ? 1 : (cb > 8 ? 8 : cb));
+        p.n_chunks = (uint32_t)((batches + p.chunk_batches - 1) / p.chunk_batches);
+        return p;
+    }
+
+    // ---------------------------------------------------------------------------------------
+    // The pass that allocates nothing (icp_hip_nn_noalloc): the kernels above with their scratch
+    // (work queue, per-chunk sums, partial rows, overflow stack) in a static device array.
+    // In host code `scratch` is only a handle: the array's device address is resolved once per
+    // device by hipGetSymbolAddress (each GPU holds its own copy at its own address) and host
+    // code uses that pointer everywhere.
+    // ---------------------------------------------------------------------------------------
+    namespace
+    {
+        static __device__ __align__(256) unsigned char scratch[kNoAllocScratchBytes];
+
+        constexpr int kMaxDevices = 64;
+        unsigned char* g_scratch_ptr[kMaxDevices] = {};
+        std::mutex g_scratch_mutex;
+
+        constexpr size_t kScrQueue = 0;
+        constexpr size_t kScrChunkSums = 4096;
+        constexpr size_t kScrPartials = kScrChunkSums + (size_t)kNoAllocMaxChunks * kCovSums * 8;
+        constexpr size_t kScrSpill = kScrPartials + (size_t)1024 * kCovSums * 8;
+        static_assert(kScrSpill + (size_t)kNoAllocSpillLevels * kNoAllocMaxBlocks * 256 * 8 ==
+                          kNoAllocScratchBytes,
+                      "scratch layout");
+        static_assert(kScrChunkSums % 256 == 0 && kScrPartials % 256 == 0 && kScrSpill % 256 == 0,
+                      "scratch regions keep the array's alignment");
+    } // namespace
+
+    hipError_t nn_noalloc_setup(int device)
+    {
+        if (device < 0 || device >= kMaxDevices)
+            return hipErrorInvalidDevice;
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (g_scratch_ptr[device])
+            return hipSuccess;
+        void* ptr = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)); // the current device's copy
+        if (e != hipSuccess)
+            return e;
+        if (!ptr)
+            return hipErrorInvalidSymbol;
+        g_scratch_ptr[device] = static_cast<unsigned char*>(ptr);
+        return hipSuccess;
+    }
+
+    hipError_t launch_nn_noalloc(int device, const NnLaunch& a_in, double* sums_out, uint32_t cut,
+                                 hipStream_t s)
+    {
+        if (device < 0 || device >= kMaxDevices)
+            return hipErrorInvalidDevice;
+        unsigned char* base;
+        {
+            std::lock_guard<std::mutex> lock(g_scratch_mutex);
+            base = g_scratch_ptr[device];
+        }
+        if (!base)
+            return hipErrorNotInitialized;
+        if (a_in.n == 0 || a_in.n > kNoAllocMaxQueries ||
+            a_in.height > (uint32_t)kStackK + kNoAllocSpillLevels)
+            return hipErrorInvalidValue;
+        const TilePlan p = plan_tile(a_in.n, kNoAllocMaxBlocks, 0);
+        if ((size_t)p.n_chunks * kCovSums * 8 > kScrPartials - kScrChunkSums)
+            return hipErrorInvalidValue;
+        NnLaunch a = a_in;
+        a.grid = p.grid_blocks;
+        a.perm = nullptr;
+        a.loop = nullptr;
+        a.partials = nullptr;
+        uint32_t* queue = reinterpret_cast<uint32_t*>(base + kScrQueue);
+        double* chunk_sums = reinterpret_cast<double*>(base + kScrChunkSums);
+        double* partials = reinterpret_cast<double*>(base + kScrPartials);
+        uint2* spill = reinterpret_cast<uint2*>(base + kScrSpill);
+        // the array keeps the last call's contents: the queue heads must start at zero
+        hipError_t e = hipMemsetAsync(queue, 0, kQueueWords * sizeof(uint32_t), s);
+        if (e != hipSuccess)
+            return e;
+        const TileLaunch q{p.chunk_batches, p.batch_queries, chunk_sums, queue, spill, nullptr, cut};
+        if ((e = launch_nn_tile(a, q, s)) != hipSuccess)
+            return e;
+        if (sums_out)
+        {
+            uint32_t g1 = (p.n_chunks + 63) / 64;
+            g1 = g1 > 1024 ? 1024 : g1;
+            if ((e = launch_reduce_rows(chunk_sums, p.n_chunks, kCovSums, g1, partials, s)) != hipSuccess)
+                return e;
+            e = launch_reduce_partials(partials, g1, kCovSums, sums_out, s);
+        }
+        return e;
+    }
 
     hipError_t launch_nn_tile(const NnLaunch& a, const TileLaunch& q, hipStream_t s)
     {

@@ -176,6 +176,29 @@ int icp_hip_set_queries(icp_hip_ctx* ctx, const float* xyz_aos, uint64_t n_local
 int icp_hip_nn(icp_hip_ctx* ctx, const float mu_p[3], uint32_t* row_out, float* xyz_out,
                float* dist_out, float* kernel_ms);
 
+/* icp_hip_nn for callers that cannot allocate (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE, whose GPU path allocates
+ * and frees a dozen temporaries per iteration (libgpu/libgpu/matrix.cu:6-17).
+ * Same kernel, same answers as icp_hip_nn against the context's tree, but:
+ *   - inputs and outputs are DEVICE buffers of the caller: the queries as three arrays of n floats
+ *     (d_px, d_py, d_pz; query_i = p_i - mu_p), and per query the row (d_row_out), the fp32
+ *     distance (d_dist_out) and the matched point (d_yx, d_yy, d_yz); each output may be NULL
+ *     (the three d_y* together); results are in the caller's order;
+ *   - d_sums_out (may be NULL): 12 doubles, [0..8] sum q (x) y in find_covariance's layout
+ *     (point-3d.cc:212-236), [9] internal nodes visited, [10] bucket points scanned, [11] stack
+ *     entries spilled;
+ *   - everything is enqueued on `stream` (a hipStream_t, NULL = the default stream) and nothing
+ *     is waited for;
+ *   - the call makes no hipMalloc / hipFree / allocating library call: the kernel's work queue,
+ *     per-chunk sums and overflow stack live in a static device array of 16.4 MB that every GPU
+ *     the library runs on holds until the process ends.  Hence the limits: n <= 1,048,576
+ *     queries per call (ICP_HIP_ERR_ARG beyond) and tree height <= 32 (ICP_HIP_ERR_DEPTH), and a
+ *     grid of one workgroup per CU.  All calls on one GPU share that array: calls that overlap
+ *     on one GPU (two streams, two contexts, two threads) race; serialise them. */
+int icp_hip_nn_noalloc(icp_hip_ctx* ctx, const float* d_px, const float* d_py, const float* d_pz,
+                       uint32_t n, const float mu_p[3], uint32_t* d_row_out, float* d_dist_out,
+                       float* d_yx, float* d_yy, float* d_yz, double* d_sums_out, void* stream);
+
 /* All-reduce hook for runs sharded over several contexts: sum `count` doubles in place over all
  * shards (host memory).  Return 0 on success.  Leave unset (or set RCCL below) for one GPU. */
 typedef int (*icp_hip_allreduce_fn)(double* values, int count, void* user);
