@@ -480,20 +480,50 @@ namespace icp_host
                 }
             }
         }
+        // every row of the cloud owns exactly one place (a node centre or a bucket slot)
+        std::vector<uint8_t> row_seen(t->n_points, 0);
         for (uint32_t i = 0; i < t->n_nodes; ++i)
+        {
             if (!node_seen[i])
                 return fail("unreachable internal node");
+            if (row_seen[t->node_row[i]]++)
+                return fail("a row is owned twice");
+        }
+        // buckets: left to right in slot order, each starting at a multiple of 16 slots (the
+        // kernels load them with 16-byte accesses), disjoint; every slot outside a bucket is
+        // padding: +inf coordinates, row 0xFFFFFFFF
+        const float inf = std::numeric_limits<float>::infinity();
+        auto padding_ok = [&](uint64_t from, uint64_t to) {
+            for (uint64_t k = from; k < to; ++k)
+                if (t->slot_x[k] != inf || t->slot_y[k] != inf || t->slot_z[k] != inf ||
+                    t->slot_row[k] != 0xFFFFFFFFu)
+                    return false;
+            return true;
+        };
+        uint64_t next_free = 0;
         for (uint32_t l = 0; l < t->n_leaves; ++l)
         {
             if (!leaf_seen[l])
                 return fail("unreachable leaf");
             if (t->leaf_count[l] == 0)
                 return fail("empty leaf bucket");
+            if (t->leaf_begin[l] % 16u != 0)
+                return fail("leaf bucket does not start at a multiple of 16 slots");
             if ((uint64_t)t->leaf_begin[l] + t->leaf_count[l] > t->n_slots)
                 return fail("leaf bucket exceeds n_slots");
+            if (t->leaf_begin[l] < next_free)
+                return fail("leaf buckets overlap or are not in left-to-right order");
+            if (!padding_ok(next_free, t->leaf_begin[l]))
+                return fail("padding slot without +inf coordinates / row 0xFFFFFFFF");
+            next_free = (uint64_t)t->leaf_begin[l] + t->leaf_count[l];
             for (uint32_t k = 0; k < t->leaf_count[l]; ++k)
-                if (t->slot_row[t->leaf_begin[l] + k] >= t->n_points)
+            {
+                const uint32_t row = t->slot_row[t->leaf_begin[l] + k];
+                if (row >= t->n_points)
                     return fail("slot row out of range");
+                if (row_seen[row]++)
+                    return fail("a row is owned twice");
+            }
             if (!all_finite(t->slot_x + t->leaf_begin[l], t->leaf_count[l]) ||
                 !all_finite(t->slot_y + t->leaf_begin[l], t->leaf_count[l]) ||
                 !all_finite(t->slot_z + t->leaf_begin[l], t->leaf_count[l]))
@@ -501,6 +531,8 @@ namespace icp_host
             pts += t->leaf_count[l];
             max_leaf = std::max(max_leaf, t->leaf_count[l]);
         }
+        if (!padding_ok(next_free, t->n_slots))
+            return fail("padding slot without +inf coordinates / row 0xFFFFFFFF");
         if (pts + t->n_nodes != t->n_points)
             return fail("n_points != n_nodes + sum(leaf_count)");
         if (height != t->height)

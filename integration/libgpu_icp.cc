@@ -16,6 +16,12 @@
 
 #include "icp_hip.h"
 #include "libgpu/icp.hh"
+#ifdef ICP_HIP_TREE_FROM_LIBCPU
+// keep building the tree with libcpu::VPTree, as libgpu::icp does (libgpu/libgpu/icp.cu:141-142),
+// and hand it over through the friend hook (libcpu/libcpu/vp-tree.hh:8-17)
+#include "flatten_from_libcpu.hh"
+#include "libcpu/vp-tree.hh"
+#endif
 
 namespace
 {
@@ -56,12 +62,29 @@ namespace libgpu
         uint64_t iters = 0;
         float error = 0;
         libcpu::point_list new_p(p.size());
+#ifdef ICP_HIP_TREE_FROM_LIBCPU
+        // icp.cu:139-142 step by step: mu_m, the host tree over m - mu_m, flattened by the friend
+        // class and uploaded in bulk (vp-tree.cu:58-112 copies it node by node), then the loop
+        const libcpu::Point3D mu = libcpu::mean(m);
+        const libcpu::point_list centred = libcpu::subtract(m, mu);
+        const libcpu::VPTree cpu_tree(vp_threshold, centred);
+        GPUVPTree::Flat flat;
+        GPUVPTree::from_cpu(cpu_tree, vp_threshold, &centred, flat);
+        check(icp_hip_set_tree(ctx.c, &flat.view), ctx.c);
+        check(icp_hip_set_queries(ctx.c, p_xyz, p.size(), p.size()), ctx.c);
+        const float mu_m[3] = {mu.x, mu.y, mu.z};
+        check(icp_hip_run(ctx.c, mu_m, iterations, threshold, T, &iters, &error, progress, nullptr),
+              ctx.c);
+        check(icp_hip_get_points(ctx.c, reinterpret_cast<float*>(new_p.data())), ctx.c);
+        (void)m_xyz;
+#else
         // mean(m), the tree over m - mean(m) (built in HBM; the reference builds it on the host
         // and copies it node by node, icp.cu:141-142, vp-tree.cu:58-112), the loop, the download
         check(icp_hip_icp(ctx.c, m_xyz, m.size(), p_xyz, p.size(), iterations, threshold,
                           vp_threshold, T, reinterpret_cast<float*>(new_p.data()), &iters, &error,
                           progress, nullptr),
               ctx.c);
+#endif
 
         utils::Matrix<float> transformation(4, 4);
         for (size_t i = 0; i < 4; ++i)

@@ -119,6 +119,20 @@ def test_validate_rejects_malformed_trees():
     s, _ = corrupted()
     s.height += 1
     assert L.icp_hip_tree_validate(C.byref(s)) == 1
+    # what the header promises about buckets and the kernels rely on: 16-slot alignment, +inf /
+    # 0xFFFFFFFF padding, disjoint buckets, every row owned exactly once
+    b1, c1 = int(ft.leaf_begin[1]), int(ft.leaf_count[1])
+    pad = b1 + c1  # first padding slot behind bucket 1 (buckets of this tree are not full)
+    assert pad % 16 != 0 and ft.slot_row[pad] == 0xFFFFFFFF and np.isinf(ft.slot_x[pad])
+    for kw in (dict(leaf_begin=(1, b1 + 4)),                       # not a multiple of 16
+               dict(slot_x=(pad, 0.0)), dict(slot_z=(pad, np.nan)),  # padding must be +inf
+               dict(slot_row=(pad, 7)),                            # padding row
+               dict(leaf_begin=(2, b1)),                           # overlaps bucket 1
+               dict(slot_row=(b1, int(ft.slot_row[b1 + 1]))),      # a row owned twice
+               dict(node_row=(0, int(ft.slot_row[b1])))):          # ... by a node and a slot
+        s, keep = corrupted(**kw)
+        assert L.icp_hip_tree_validate(C.byref(s)) == 1, kw
+        assert b"icp_hip_tree_validate" in L.icp_hip_last_global_error()
     ft.close()
 
 
