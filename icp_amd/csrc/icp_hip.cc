@@ -305,7 +305,7 @@ namespace
         {
             const char* env = std::getenv("ICP_HIP_TILE_STATS");
             if (env && env[0] == '1')
-                HIP_TRY(c, c->stats.alloc(8));
+                HIP_TRY(c, c->stats.alloc(24));
         }
         HIP_TRY(c, c->chunk_sums.alloc((size_t)c->n_chunks * kCovSums));
         HIP_TRY(c, c->spill.alloc((size_t)c->spill_levels * c->tile_grid_blocks * 256));
@@ -343,7 +343,7 @@ namespace
         TileLaunch q{c->chunk_batches, c->batch_queries, c->chunk_sums.p, c->queue.p,
                      c->spill.p, loop ? nullptr : c->stats.p, c->tile_cut};
         if (q.stats)
-            HIP_TRY(c, hipMemsetAsync(q.stats, 0, 8 * sizeof(unsigned long long), c->stream));
+            HIP_TRY(c, hipMemsetAsync(q.stats, 0, 24 * sizeof(unsigned long long), c->stream));
         if (e0)
             HIP_TRY(c, hipEventRecord(e0, c->stream));
         HIP_TRY(c, launch_nn_tile(a, q, c->stream));
@@ -351,14 +351,18 @@ namespace
             HIP_TRY(c, hipEventRecord(e1, c->stream));
         if (q.stats)
         {
-            unsigned long long h[8];
+            unsigned long long h[24];
             HIP_TRY(c, hipMemcpyAsync(h, q.stats, sizeof h, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             std::fprintf(stderr,
                          "[tile stats] batches %llu node_iters %llu node_lane_steps %llu "
                          "leaf_phases %llu tile_scans %llu tile_lanes %llu coop_scans %llu "
-                         "exact_scans %llu\n",
-                         h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+                         "exact_scans %llu | wave cycles: total %llu head %llu node %llu leaf %llu "
+                         "(tile %llu: stage %llu mfma %llu finish %llu, image reused %llu) exact+served "
+                         "%llu tail %llu | cache-hit node_iters %llu | shader clock %.0f MHz | queue pops %llu cycles | longest wave %llu cycles, most batches in a wave %llu\n",
+                         h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11],
+                         h[12], h[16], h[17], h[18], h[19], h[13], h[14], h[15],
+                         h[20] ? 100.0 * (double)h[8] / (double)h[20] : 0.0, h[21], h[22], h[23]);
         }
         // chunk sums -> <= 1024 partial rows -> the twelve sums, both in a fixed order
         uint32_t g1 = (c->n_chunks + 63) / 64;
@@ -1015,6 +1019,9 @@ extern "C"
             // the static scratch array of icp_hip_nn_noalloc: its address on this device
             if ((e = nn_noalloc_setup(device_id)) != hipSuccess)
                 return bail(e, "hipGetSymbolAddress(scratch)");
+            if (const char* w = std::getenv("ICP_HIP_TILE_WGS_PER_CU")) // experiments only
+                if (std::atoi(w) > 0 && std::atoi(w) < per_cu)
+                    per_cu = std::atoi(w);
             uint64_t blocks = (uint64_t)(per_cu > 0 ? per_cu : 1) * (uint64_t)(cus > 0 ? cus : 1);
             if (blocks > kNnMaxBlocks)
                 blocks = kNnMaxBlocks;
