@@ -21,6 +21,19 @@ namespace icp_dev
         return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
     }
 
+    // The same sum with fused multiply-adds: NOT the reference's rounding (three roundings instead
+    // of five, each within 2^-24 of its partial sum: like the reference's value it lies within
+    // 3.01 * 2^-24 of the real sum of squares of the three fp32 differences).  Only ever a filter:
+    // an answer is always re-evaluated with sq_dist.
+    __device__ __forceinline__ float sq_dist_fma(float ax, float ay, float az, float bx, float by,
+                                                 float bz)
+    {
+        const float dx = __fsub_rn(ax, bx);
+        const float dy = __fsub_rn(ay, by);
+        const float dz = __fsub_rn(az, bz);
+        return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
+    }
+
     __device__ __forceinline__ float readlane_f(float v, int l)
     {
         return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));

@@ -358,11 +358,11 @@ namespace
                          "[tile stats] batches %llu node_iters %llu node_lane_steps %llu "
                          "leaf_phases %llu tile_scans %llu tile_lanes %llu coop_scans %llu "
                          "exact_scans %llu | wave cycles: total %llu head %llu node %llu leaf %llu "
-                         "(tile %llu: stage %llu mfma %llu finish %llu, image reused %llu) exact+served "
-                         "%llu tail %llu | cache-hit node_iters %llu | shader clock %.0f MHz | queue pops %llu cycles | longest wave %llu cycles, most batches in a wave %llu\n",
+                         "(tile %llu) exact+served %llu tail %llu queue pops %llu | shader clock "
+                         "%.0f MHz | longest wave %llu cycles, most batches in a wave %llu\n",
                          h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11],
-                         h[12], h[16], h[17], h[18], h[19], h[13], h[14], h[15],
-                         h[20] ? 100.0 * (double)h[8] / (double)h[20] : 0.0, h[21], h[22], h[23]);
+                         h[12], h[13], h[14], h[21],
+                         h[20] ? 100.0 * (double)h[8] / (double)h[20] : 0.0, h[22], h[23]);
         }
         // chunk sums -> <= 1024 partial rows -> the twelve sums, both in a fixed order
         uint32_t g1 = (c->n_chunks + 63) / 64;

@@ -111,7 +111,7 @@ namespace icp_dev
         uint32_t* queue;        // kQueueWords words, zero at launch; the last workgroup to finish
                                 // leaves them zero for the next launch
         uint2* spill;           // [max(0, height - stack entries)][grid * 256] or null
-        unsigned long long* stats; // 8 event counters of the diagnostic build, or null
+        unsigned long long* stats; // 24 counters of the diagnostic build (events, cycles by phase), or null
         uint32_t cut; // leave the node phase when waiting lanes >= cut/16 x stepping lanes (0: never)
     };
     hipError_t launch_nn_tile(const NnLaunch& a, const TileLaunch& q, hipStream_t s);

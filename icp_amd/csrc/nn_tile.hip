@@ -16,27 +16,27 @@
 //    searched (push on the way into the far side, pop on the way back): 4 entries per lane in
 //    LDS instead of one per tree level; deeper nestings spill to a per-lane column in HBM
 //    (counted in sum [11]);
-//  * leaf buckets are scanned as (bucket points x queries) tiles on the matrix cores: the g lanes
-//    of a wave that wait on the SAME bucket are served together.  The bucket is staged once in
-//    LDS relative to its first point o (p' = p - o, w = |p'|^2), the queries likewise
-//    (q' = q - o), and v_mfma_f32_16x16x4_f32 evaluates  w - 2 q'.p'  (= |q - p|^2 - |q'|^2 up
-//    to rounding) for 16 points x 16 queries per instruction; the vector ALU only keeps, per
-//    query, the smallest and second smallest value and where the smallest was.  This is a
-//    FILTER, not the answer: see "Exactness" below.  One or two waiting lanes are served by a
-//    whole-wave scan instead (coop_scan).
+//  * leaf buckets are scanned by (queries x bucket parts) tiles: the g lanes of a wave that wait
+//    on the SAME bucket are served together.  The bucket is staged once in LDS (three 16-byte
+//    loads per lane), the g queries are replicated over P = 64 / pow2(g) lane groups, group p
+//    scans part p of the bucket for all g queries (LDS float4 reads, conflict free by
+//    construction), and the partial minima are folded across the groups.  g = 1 degenerates to
+//    the whole wave scanning for one query, g = 64 to one lane per query.
 //
 // Exactness of the bucket scan.  The reference keeps the first slot that minimises
 // sqrt(d2) under strict < (vp-tree.cc:131-143), d2 = ((dx*dx)+(dy*dy))+(dz*dz) in fp32 without
-// FMA; two different d2 may share one sqrt.  The matrix-core values differ from d2 - |q'|^2 by at
-// most E0 = 9.01 u L^2 (u = 2^-24, L = |q'| + max |p'|; derivation at tile_scan).  The four
-// points of the winning group are re-evaluated with the reference's arithmetic; their minimum m
-// is the reference's answer with distance sqrt(m) iff (i) the runner-up inside the group is
-// more than 4 ulps above m (then the roots differ by >= 1.41 ulps of the root and round to
-// different floats) and (ii) the second smallest filter value exceeds the smallest by more than
-// 2.5 E + 32 u max(m, filter minimum) with E = 32 u (|q'|^2 + max |p'|^2) >= 1.77 E0: then
-// every point outside the group has a reference d2 more than 4 ulps above m.  Otherwise (about
-// 1e-3 of the scans; every exact tie and duplicate point) the lane is re-served by the exact
-// wave-cooperative scan of device_common.hh.
+// FMA; two different d2 may share one sqrt.  The scan loop evaluates a FILTER instead,
+// fma(dz,dz, fma(dy,dy, dx*dx)) (six operations instead of eight; like d2 it lies within 3.01 u,
+// u = 2^-24, of the real sum of squares of the same three differences), and tracks per query the
+// smallest group minimum m, the second smallest m2 (with multiplicity) and m's group.  The four
+// points of that group are then re-evaluated with the reference's arithmetic: em = their smallest
+// d2, e2 the runner-up inside the group.  The slot of em is the reference's answer, with distance
+// sqrt(em), iff (i) e2 is more than 4 ulps above em (then the roots differ by >= 1.41 ulps of the
+// root and round to different floats) and (ii) m2 is more than 16 float steps above em: a point
+// outside the group has a filter value >= m2 and a reference d2 >= its filter value x (1 - 6.03 u),
+// hence more than 4 ulps above em as well.  Otherwise (about 2e-4 of the scans; every exact tie
+// and duplicate point) the lane is re-served by the exact wave-cooperative scan of
+// device_common.hh.
 
 #include <hip/hip_runtime.h>
 #include <stddef.h>
@@ -51,11 +51,11 @@ namespace icp_dev
 {
     namespace
     {
-        constexpr int kStackK = 3;  // LDS stack entries per lane
+        constexpr int kStackK = 4;  // LDS stack entries per lane
         constexpr int kImage = 256; // bucket slots staged per window
+        constexpr int kGroups = kImage / 4; // float4 groups of the image; group kGroups is +inf
         constexpr int kTileMinGroup = 3; // fewer lanes on a bucket: whole-wave scan per lane
-        constexpr int kPathLevels = 20;  // levels of the node-record cache (deeper nodes: L2)
-        using f32x4 = __attribute__((ext_vector_type(4))) float;
+        constexpr int kTileSplitBelow = 56; // 33..55 lanes: scan as 32 + rest (see the leaf phase)
 
         enum : int
         {
@@ -67,21 +67,19 @@ namespace icp_dev
             tDone = 5
         };
 
-        struct __attribute__((aligned(32))) WaveLds
+        struct __attribute__((aligned(16))) WaveLds
         {
             float st_d[kStackK * kWave];
             uint32_t st_i[kStackK * kWave];
-            float img[4 * kImage]; // bucket window: x[256] y[256] z[256] as stored in the tree (slots
-                                   // that are not the bucket's hold the origin o) and
-                                   // |p - o|^2[256] (+inf there); matrix operand A = img - (o, 0)
-            float4 qb[kWave]; // queries by rank in the group (matrix operand B), then their results
-            // node records of the last descent, by tree level: the queries of consecutive batches
-            // take almost the same path, so most node visits are served from here instead of L2
-            uint32_t pc_tag[kPathLevels];
-            DevNode pc_rec[kPathLevels];
+            float bx[kImage + 4], by[kImage + 4], bz[kImage + 4]; // + the all-inf float4 group
+            float4 qb[kWave]; // queries by rank in the group, then their results
             double sums[kCovSums + 4]; // this wave's running totals (fixed summation order)
         };
-        static_assert(sizeof(WaveLds) <= 8192, "LDS budget: 4 waves x 8 KiB = 32 KiB per workgroup, 5 per CU");
+        static_assert(sizeof(WaveLds) <= 8192, "LDS budget: 4 waves x 8 KiB = 32 KiB per workgroup");
+        static_assert(offsetof(WaveLds, by) - offsetof(WaveLds, bx) == (kImage + 4) * sizeof(float) &&
+                          offsetof(WaveLds, bz) - offsetof(WaveLds, by) == (kImage + 4) * sizeof(float),
+                      "tile_scan addresses by and bz relative to bx");
+
         __device__ __forceinline__ void wave_lds_fence()
         {
             // LDS operations of one wave execute in order; this only pins the compiler
@@ -140,256 +138,170 @@ namespace icp_dev
             return v;
         }
 
-        // Largest of a non-negative float over the wave (wave-uniform result).
-        __device__ __forceinline__ float wave_max_nonneg(float v)
-        {
-            int x = __float_as_int(v);
-            x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x111, 0xf, 0xf, false)); // row_shr:1
-            x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x112, 0xf, 0xf, false)); // row_shr:2
-            x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x114, 0xf, 0xf, false)); // row_shr:4
-            x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x118, 0xf, 0xf, false)); // row_shr:8
-            x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x142, 0xa, 0xf, false)); // row_bcast:15
-            x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x143, 0xc, 0xf, false)); // row_bcast:31
-            return __int_as_float(__builtin_amdgcn_readlane(x, 63));
-        }
-
         // Tile scan of bucket [beg, beg+cnt) for the g lanes in `grp` (all of them wait on it).
-        //
-        // Filter (matrix cores).  o = the bucket's first point.  Staged: p' = fl(p - o) and
-        // w = fl-chain |p'|^2 per slot (+inf, with p' = 0, in slots that are not the bucket's),
-        // B = (-2 q'_x, -2 q'_y, -2 q'_z, 1) per query with q' = fl(q - o).  One
-        // v_mfma_f32_16x16x4_f32 gives D[point i][query n] = fma-chain(w_i - 2 q'_n . p'_i) for 16
-        // points x 16 queries: lane l holds, for query l & 15 of the tile, the four points
-        // 16 (l >> 4) + 4 r + s (r = 0..3) of a 64-slot stretch, s = the instruction's number in
-        // the stretch (its A operand is component s of one ds_read_b128).  Per query tile the
-        // lane keeps the smallest group minimum, the second smallest (with multiplicity) and
-        // the code of the smallest's group; the four lanes l & 15 + 16 h share a query and are
-        // folded at the end.
-        //
-        // Error of the filter.  With S = the real |q - p|^2 of the float inputs, c = |q'|^2 and
-        // u = 2^-24:  q - o = q' (1 + e), p - o = p' (1 + e'), |e|, |e'| <= u, so S differs from
-        // S' = |q' - p'|^2 by at most 2 sqrt(S') u L + u^2 L^2, L = |q'| + |p'|; w carries 3 u |p'|^2;
-        // the four roundings of the chain are each at most u (|p'|^2 + 2 |q'| |p'|) whatever their
-        // order (partial sums of a dot product are bounded by the product of the norms).  Hence
-        // |D + c - S| <= (2 + 3 + 4 + small) u L^2 <= 9.01 u L^2 =: E0, and L^2 <= 2 (c + max w).
-        // The reference's own d2 is within 6 u S of S.  Member lanes then decide as described at
-        // the top of the file; a bound that is too large only sends more lanes to the exact scan.
-        //
-        // On return a member lane has: out_m = the reference's d2 of the best point of the
-        // winning group, out_idx = that point's slot in the bucket, out_ok = whether it is
-        // proven to be the reference's answer.
-        template <bool STATS>
+        // The 64 lanes form P = 64/g parts of g lanes; lane (part p, slot s) scans the float4
+        // groups p, p+P, p+2P, .. of the staged image for the query of rank s.  Inside the loop
+        // only the minimum of each float4 group of the FILTER values is tracked (its step, the
+        // smallest and the second smallest group minimum); the winning group is re-read once at
+        // the end and evaluated with the reference's arithmetic.  On return every member lane has
+        // out_m = the reference's d2 of the best point of that group, out_idx = its slot in the
+        // bucket, out_ok = whether it is proven to be the reference's answer (top of the file).
         __device__ __forceinline__ void tile_scan(const DevTree& t, WaveLds& L, uint32_t beg,
                                                   uint32_t cnt, uint64_t grp, bool member, float qx,
                                                   float qy, float qz, int lane, float& out_m,
                                                   bool& out_ok, uint32_t& out_idx,
-                                                  uint32_t& staged, float& img_r2,
-                                                  unsigned long long* cyc)
+                                                  uint32_t& staged)
         {
             const float kInf = __int_as_float(0x7f800000);
-            const unsigned long long c0 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
             const uint32_t g = (uint32_t)__builtin_popcountll(grp); // 1..64
-            const uint32_t T = (g + 15u) >> 4;                      // query tiles of 16
+            const uint32_t P = 64u / g;
+            // lane / g for lane < 64 (exact for every g in 1..64)
+            const uint32_t part = ((uint32_t)lane * (65536u / g + 1u)) >> 16;
+            const uint32_t slot = (uint32_t)lane - part * g;
+            const bool idle = part >= P; // lanes past the last whole part read the +inf group
+
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi(
                 (uint32_t)(grp >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)grp, 0u));
-            const bool single = cnt <= (uint32_t)kImage;
-            const bool have_image = single && staged == beg;
-            // first window's slots and the origin (the bucket's first point; wave-uniform): all
-            // loads are issued before the first use, one round trip
-            const uint32_t s0 = 4u * (uint32_t)lane;
-            float4 X = make_float4(0.f, 0.f, 0.f, 0.f), Y = X, Z = X;
-            if (!have_image && s0 < cnt)
-            {
-                const size_t o = (size_t)beg + s0;
-                X = *reinterpret_cast<const float4*>(t.sx + o);
-                Y = *reinterpret_cast<const float4*>(t.sy + o);
-                Z = *reinterpret_cast<const float4*>(t.sz + o);
-            }
-            const float ox = t.sx[beg], oy = t.sy[beg], oz = t.sz[beg];
-            const float qpx = __fsub_rn(qx, ox), qpy = __fsub_rn(qy, oy), qpz = __fsub_rn(qz, oz);
             if (member)
-                L.qb[rank] = make_float4(__fmul_rn(qpx, -2.f), __fmul_rn(qpy, -2.f),
-                                         __fmul_rn(qpz, -2.f), 1.f);
-            const uint32_t lrow = (uint32_t)lane >> 4, lcol = (uint32_t)lane & 15u;
-            // operand A: component lrow of the points 4 lcol .. 4 lcol + 3 of a 64-slot stretch,
-            // relative to the origin (row 3 is |p'|^2 as staged)
-            const float* const a_base = L.img + lrow * (uint32_t)kImage + 4u * lcol;
-            const float a_sub = lrow == 0u ? ox : lrow == 1u ? oy : lrow == 2u ? oz : 0.f;
-            float r2 = have_image ? img_r2 : 0.f;
-            // stage one window of the bucket (`staged` = first slot of the bucket whose only
-            // window the image holds: the batches of a chunk that share a bucket stage it once)
-            auto stage = [&](uint32_t w0, uint32_t cw, bool preloaded) {
-                if (!preloaded)
+                L.qb[rank] = make_float4(qx, qy, qz, 0.f);
+
+            // m, m2: smallest and second smallest group minimum of the FILTER values
+            // fma(dz,dz, fma(dy,dy, dx*dx)); em: the reference's d2 of the best point of the
+            // filter's winning group; idx: its slot, bit 31 = the runner-up inside that group is
+            // more than 4 ulps above em
+            float m = kInf, m2 = kInf, em = kInf;
+            uint32_t idx = 0;
+#pragma nounroll
+            for (uint32_t w0 = 0; w0 < cnt; w0 += kImage) // one window unless the bucket is > 256
+            {
+                const uint32_t cw = min((uint32_t)kImage, cnt - w0);
+                // ---- stage the window: x is +inf in every slot that is not the bucket's ----
+                // (`staged` = first slot of the window the image holds: the batches of a chunk
+                // that share a bucket, and the two halves of a split group, stage it once)
+                if (staged != beg + w0)
                 {
-                    X = Y = Z = make_float4(0.f, 0.f, 0.f, 0.f);
+                    staged = beg + w0;
+                    const uint32_t s0 = 4u * (uint32_t)lane;
+                    float4 vx = make_float4(kInf, kInf, kInf, kInf);
+                    float4 vy = make_float4(0.f, 0.f, 0.f, 0.f), vz = vy;
                     if (s0 < cw)
                     {
                         const size_t o = (size_t)beg + w0 + s0;
-                        X = *reinterpret_cast<const float4*>(t.sx + o);
-                        Y = *reinterpret_cast<const float4*>(t.sy + o);
-                        Z = *reinterpret_cast<const float4*>(t.sz + o);
+                        vx = *reinterpret_cast<const float4*>(t.sx + o);
+                        vy = *reinterpret_cast<const float4*>(t.sy + o);
+                        vz = *reinterpret_cast<const float4*>(t.sz + o);
+                        vx.y = (s0 + 1u < cw) ? vx.y : kInf;
+                        vx.z = (s0 + 2u < cw) ? vx.z : kInf;
+                        vx.w = (s0 + 3u < cw) ? vx.w : kInf;
                     }
+                    *reinterpret_cast<float4*>(L.bx + s0) = vx;
+                    *reinterpret_cast<float4*>(L.by + s0) = vy;
+                    *reinterpret_cast<float4*>(L.bz + s0) = vz;
                 }
-                float4 vw;
-                auto rel = [&](float& x, float& y, float& z, bool in, float& rw) {
-                    x = in ? x : ox;
-                    y = in ? y : oy;
-                    z = in ? z : oz;
-                    const float dx = __fsub_rn(x, ox), dy = __fsub_rn(y, oy), dz = __fsub_rn(z, oz);
-                    const float w = __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
-                    rw = in ? w : kInf;
+                wave_lds_fence();
+                const float4 q = L.qb[slot];
+                const uint32_t n4 = (cw + 3u) >> 2;           // float4 groups in the window
+                const uint32_t steps = (n4 + P - 1u) / P;     // wave-uniform
+                // byte offset of this lane's float4 group in bx/by/bz.  Lanes past the last whole
+                // part shadow part 0: nothing folds their results in.  Every group below kGroups
+                // is staged (+inf behind the bucket), group kGroups is the +inf pad; only a scan
+                // that can step past it (P * steps > kGroups + 1: long buckets in many parts)
+                // clamps its offsets.
+                const char* const img = reinterpret_cast<const char*>(L.bx);
+                const char* gp = img + (idle ? 0u : 16u * part); // this lane's group in bx
+                const uint32_t gstride = 16u * P;
+                const float m_before = m;
+                const char* bp = img; // group of the smallest minimum so far
+                constexpr uint32_t kBy = (kImage + 4) * sizeof(float), kBz = 2u * kBy;
+                auto step = [&](const char* at) {
+                    const float4 X = *reinterpret_cast<const float4*>(at);
+                    const float4 Y = *reinterpret_cast<const float4*>(at + kBy);
+                    const float4 Z = *reinterpret_cast<const float4*>(at + kBz);
+                    const float d0 = sq_dist_fma(q.x, q.y, q.z, X.x, Y.x, Z.x);
+                    const float d1 = sq_dist_fma(q.x, q.y, q.z, X.y, Y.y, Z.y);
+                    const float d2 = sq_dist_fma(q.x, q.y, q.z, X.z, Y.z, Z.z);
+                    const float d3 = sq_dist_fma(q.x, q.y, q.z, X.w, Y.w, Z.w);
+                    const float gm = fminf(fminf(fminf(d0, d1), d2), d3);
+                    bp = (gm < m) ? at : bp;
+                    m2 = __builtin_amdgcn_fmed3f(m, m2, gm);
+                    // distances are >= 0 (or +inf): they order like their bit patterns
+                    m = __uint_as_float(min(__float_as_uint(m), __float_as_uint(gm)));
                 };
-                rel(X.x, Y.x, Z.x, s0 < cw, vw.x);
-                rel(X.y, Y.y, Z.y, s0 + 1u < cw, vw.y);
-                rel(X.z, Y.z, Z.z, s0 + 2u < cw, vw.z);
-                rel(X.w, Y.w, Z.w, s0 + 3u < cw, vw.w);
-                *reinterpret_cast<float4*>(L.img + s0) = X;
-                *reinterpret_cast<float4*>(L.img + kImage + s0) = Y;
-                *reinterpret_cast<float4*>(L.img + 2 * kImage + s0) = Z;
-                *reinterpret_cast<float4*>(L.img + 3 * kImage + s0) = vw;
-                // max |p'|^2 over the window's real slots
-                float wmax = 0.f;
-                wmax = fmaxf(wmax, vw.x == kInf ? 0.f : vw.x);
-                wmax = fmaxf(wmax, vw.y == kInf ? 0.f : vw.y);
-                wmax = fmaxf(wmax, vw.z == kInf ? 0.f : vw.z);
-                wmax = fmaxf(wmax, vw.w == kInf ? 0.f : vw.w);
-                r2 = fmaxf(r2, wave_max_nonneg(wmax));
-            };
-            if (single && !have_image)
-            {
-                stage(0u, cnt, true);
-                staged = beg;
-            }
-            if (!single)
-                staged = 0xFFFFFFFFu;
-            wave_lds_fence();
-            const unsigned long long c1 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
-            const float* const qf = reinterpret_cast<const float*>(L.qb);
-            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-            // one query tile (16 queries) at a time: the state of a tile is three registers
-#pragma nounroll
-            for (uint32_t q = 0; q < T; ++q)
-            {
-                // operand B: component lrow of query 16 q + lcol
-                const float bq = qf[(16u * q + lcol) * 4u + lrow];
-                float m = kInf, m2 = kInf;
-                uint32_t best = 0u;
-#pragma nounroll
-                for (uint32_t w0 = 0; w0 < cnt; w0 += kImage) // one window unless the bucket is > 256
+                if (P * steps <= (uint32_t)kGroups + 1u)
                 {
-                    const uint32_t cw = min((uint32_t)kImage, cnt - w0);
-                    if (!single)
+#pragma unroll 2
+                    for (uint32_t k = 0; k < steps; ++k)
                     {
-                        wave_lds_fence(); // the window before has been read
-                        stage(w0, cw, q == 0u && w0 == 0u);
-                        wave_lds_fence();
-                    }
-                    const uint32_t nJ = (cw + 63u) >> 6;
-                    float4 An = *reinterpret_cast<const float4*>(a_base);
-#pragma nounroll
-                    for (uint32_t J = 0; J < nJ; ++J)
-                    {
-                        float4 A4 = An;
-                        // the next stretch's operand is on its way while this one is multiplied
-                        // (stretch 3 wraps to 0: a harmless re-read inside the image)
-                        An = *reinterpret_cast<const float4*>(a_base + 64u * ((J + 1u) & 3u));
-                        A4.x = __fsub_rn(A4.x, a_sub); // p' = fl(p - o), the subtraction w was made from
-                        A4.y = __fsub_rn(A4.y, a_sub);
-                        A4.z = __fsub_rn(A4.z, a_sub);
-                        A4.w = __fsub_rn(A4.w, a_sub);
-                        const uint32_t code0 = ((w0 >> 6) + J) << 2;
-                        // the four products are issued back to back, then looked at
-                        const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A4.x, bq, zero, 0, 0, 0);
-                        const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A4.y, bq, zero, 0, 0, 0);
-                        const f32x4 d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(A4.z, bq, zero, 0, 0, 0);
-                        const f32x4 d3 = __builtin_amdgcn_mfma_f32_16x16x4f32(A4.w, bq, zero, 0, 0, 0);
-                        auto track = [&](const f32x4& d, uint32_t code) {
-                            const float gm = fminf(fminf(d[0], d[1]), fminf(d[2], d[3]));
-                            best = (gm < m) ? code : best;
-                            m2 = __builtin_amdgcn_fmed3f(m, m2, gm);
-                            m = fminf(m, gm);
-                        };
-                        track(d0, code0);
-                        track(d1, code0 + 1u);
-                        track(d2, code0 + 2u);
-                        track(d3, code0 + 3u);
+                        step(gp);
+                        gp += gstride;
                     }
                 }
-                // fold the four lanes (rows) that share the query: rows 0|1 and 2|3 by
-                // v_permlane16_swap, then the halves by v_permlane32_swap (no LDS traffic);
-                // ties keep either side: m2 == m then, and the lane goes to the exact scan
-                uint32_t b = best | (lrow << 28);
-                auto fold = [&](auto swap) {
-                    const auto sm = swap(__float_as_uint(m), __float_as_uint(m), false, false);
-                    const auto s2 = swap(__float_as_uint(m2), __float_as_uint(m2), false, false);
-                    const auto sb = swap(b, b, false, false);
-                    const float ma = __uint_as_float(sm[0]), mb = __uint_as_float(sm[1]);
-                    m2 = fminf(fminf(__uint_as_float(s2[0]), __uint_as_float(s2[1])), fmaxf(ma, mb));
-                    b = (mb < ma) ? sb[1] : sb[0];
-                    m = fminf(ma, mb);
-                };
-                fold([](uint32_t x, uint32_t y, bool a, bool c) {
-                    return __builtin_amdgcn_permlane16_swap(x, y, false, false);
-                });
-                fold([](uint32_t x, uint32_t y, bool a, bool c) {
-                    return __builtin_amdgcn_permlane32_swap(x, y, false, false);
-                });
-                if (lrow == 0u) // row 0 publishes by rank (this tile's queries have been read)
-                    L.qb[16u * q + lcol] = make_float4(m, m2, __uint_as_float(b), 0.f);
+                else
+                {
+                    const char* const pad = img + 16u * (uint32_t)kGroups;
+#pragma nounroll
+                    for (uint32_t k = 0; k < steps; ++k)
+                    {
+                        step(gp < pad ? gp : pad);
+                        gp += gstride;
+                    }
+                }
+                if (m < m_before)
+                {
+                    // the winning group again: slot of m and the runner-up inside the group
+                    const float4 X = *reinterpret_cast<const float4*>(bp);
+                    const float4 Y = *reinterpret_cast<const float4*>(bp + kBy);
+                    const float4 Z = *reinterpret_cast<const float4*>(bp + kBz);
+                    const float d0 = sq_dist(q.x, q.y, q.z, X.x, Y.x, Z.x);
+                    const float d1 = sq_dist(q.x, q.y, q.z, X.y, Y.y, Z.y);
+                    const float d2 = sq_dist(q.x, q.y, q.z, X.z, Y.z, Z.z);
+                    const float d3 = sq_dist(q.x, q.y, q.z, X.w, Y.w, Z.w);
+                    float a = kInf, b2 = kInf;
+                    track2(d0, a, b2);
+                    track2(d1, a, b2);
+                    track2(d2, a, b2);
+                    track2(d3, a, b2);
+                    const uint32_t c = (d0 == a) ? 0u : (d1 == a) ? 1u : (d2 == a) ? 2u : 3u;
+                    idx = w0 + ((uint32_t)(bp - img) >> 2) + c;
+                    if ((__float_as_uint(b2) - __float_as_uint(a)) > 4u)
+                        idx |= 0x80000000u;
+                    em = a;
+                }
+                wave_lds_fence(); // the next window overwrites the image
             }
-            img_r2 = r2;
-            const unsigned long long c2 = STATS ? __builtin_amdgcn_s_memtime() : 0ull;
+            // ---- fold the parts: part p takes part p + half, halving until one part is left ----
+#pragma nounroll
+            for (uint32_t h = P; h > 1u;)
+            {
+                const uint32_t half = (h + 1u) >> 1;
+                const int src = lane + (int)(half * g);
+                const float mb = __shfl(m, src, kWave);
+                const float m2b = __shfl(m2, src, kWave);
+                const float emb = __shfl(em, src, kWave);
+                const uint32_t ib = __shfl(idx, src, kWave);
+                if (part + half < h)
+                {
+                    // the part with the smaller filter minimum carries its exact pair on; a tie
+                    // leaves m2 == m and the lane goes to the exact scan
+                    idx = (mb < m) ? ib : idx;
+                    em = (mb < m) ? emb : em;
+                    m2 = fminf(fminf(m2, m2b), fmaxf(m, mb));
+                    m = fminf(m, mb);
+                }
+                h = half;
+            }
+            if ((uint32_t)lane < g)
+                L.qb[lane] = make_float4(em, m2, __uint_as_float(idx), 0.f);
             wave_lds_fence();
             const float4 r = L.qb[member ? rank : 0u];
+            out_m = r.x;
+            out_idx = __float_as_uint(r.z) & 0x7FFFFFFFu;
+            // every point outside the winning group has a filter value >= m2; filter and
+            // reference d2 are both within 3.01 u of the real sum, so m2 more than 16 float steps
+            // above em puts every such point's reference d2 more than 4 ulps above em
+            out_ok = (__float_as_uint(r.z) >> 31) != 0u &&
+                     (int)(__float_as_uint(r.y) - __float_as_uint(r.x)) > 16;
             wave_lds_fence();
-            // ---- the winning group again, with the reference's arithmetic ----
-            const float a1 = r.x, a2 = r.y;
-            const uint32_t b = __float_as_uint(r.z);
-            const uint32_t code = b & 0x0FFFFFFFu;
-            const uint32_t base = ((code >> 2) << 6) + ((b >> 28) << 4) + (code & 3u);
-            float e[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-            {
-                const uint32_t off = base + 4u * (uint32_t)k;
-                e[k] = kInf;
-                if (member && off < cnt)
-                {
-                    if (single) // the image still holds the bucket as stored in the tree
-                        e[k] = sq_dist(qx, qy, qz, L.img[off], L.img[kImage + off],
-                                       L.img[2 * kImage + off]);
-                    else
-                    {
-                        const size_t o = (size_t)beg + off;
-                        e[k] = sq_dist(qx, qy, qz, t.sx[o], t.sy[o], t.sz[o]);
-                    }
-                }
-            }
-            float em = kInf, e2 = kInf;
-            track2(e[0], em, e2);
-            track2(e[1], em, e2);
-            track2(e[2], em, e2);
-            track2(e[3], em, e2);
-            const uint32_t c = (e[0] == em) ? 0u : (e[1] == em) ? 1u : (e[2] == em) ? 2u : 3u;
-            const float cq = __fadd_rn(__fadd_rn(__fmul_rn(qpx, qpx), __fmul_rn(qpy, qpy)),
-                                       __fmul_rn(qpz, qpz));
-            // 2.5 E + 32 u max(m, filter minimum), E = 32 u (c + max w): 80 u = 4.77e-6
-            const float thr = __fadd_rn(
-                __fadd_rn(__fmul_rn(__fadd_rn(cq, r2), 4.77e-6f),
-                          __fmul_rn(fmaxf(em, __fadd_rn(a1, cq)), 1.91e-6f)),
-                1e-30f);
-            out_m = em;
-            out_idx = base + 4u * c;
-            out_ok = (__float_as_uint(e2) - __float_as_uint(em)) > 4u && em < kInf &&
-                     __fsub_rn(a2, a1) > thr;
-            if (STATS)
-            {
-                const unsigned long long c3 = __builtin_amdgcn_s_memtime();
-                cyc[0] += c1 - c0;
-                cyc[1] += c2 - c1;
-                cyc[2] += c3 - c2;
-                cyc[3] += have_image ? 1ull : 0ull;
-            }
         }
 
         // Whole-wave scan of one bucket of <= 256 slots for ONE query (arguments wave-uniform):
@@ -460,7 +372,7 @@ namespace icp_dev
     } // namespace
 
         template <bool STATS>
-        __global__ void __launch_bounds__(kBlock, 5) // 5 workgroups per CU (LDS 5 x 32 KiB, <= 96 VGPRs)
+        __global__ void __launch_bounds__(kBlock, 6) // 6 workgroups per CU (LDS 6 x 24.7 KiB, <= 80 VGPRs)
             nn_tile_kernel(DevTree t, const float* __restrict__ px, const float* __restrict__ py,
                            const float* __restrict__ pz, float mux, float muy, float muz, uint32_t n,
                            float* __restrict__ yx, float* __restrict__ yy, float* __restrict__ yz,
@@ -489,24 +401,26 @@ namespace icp_dev
                      st_exact = 0, st_leafph = 0, st_batch = 0, st_node_lanes = 0;
             // shader cycles by phase (diagnostic build only)
             unsigned long long cy_node = 0, cy_tile = 0, cy_coop = 0, cy_exact = 0, cy_tail = 0,
-                               cy_head = 0, cy_total = 0, cy_hits = 0, cy_pop = 0;
+                               cy_head = 0, cy_total = 0, cy_pop = 0;
+            const unsigned long long rt_begin = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
             auto now = [&]() -> unsigned long long {
                 return STATS ? (unsigned long long)__builtin_amdgcn_s_memtime() : 0ull;
             };
             const unsigned long long cy_begin = now();
-            const unsigned long long rt_begin = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
-            unsigned long long cy_ts[4] = {0ull, 0ull, 0ull, 0ull};
 
             const int lane = threadIdx.x & (kWave - 1);
             const int w = threadIdx.x >> 6;
             WaveLds& L = s_w[w];
             float* st_d = L.st_d + lane;
             uint32_t* st_i = L.st_i + lane;
-            if (lane < kPathLevels)
-                L.pc_tag[lane] = 0xFFFFFFFFu;
-            uint32_t staged = 0xFFFFFFFFu; // wave-uniform: bucket whose image is in LDS
-            float img_r2 = 0.f;            // wave-uniform: max |p'|^2 of that image
-            uint32_t staged_cnt = 0;       // wave-uniform: slots of that bucket
+            if (lane < 4)
+            {
+                L.bx[kImage + lane] = __int_as_float(0x7f800000);
+                L.by[kImage + lane] = 0.f;
+                L.bz[kImage + lane] = 0.f;
+            }
+            uint32_t staged = 0xFFFFFFFFu; // wave-uniform: window of the bucket image in LDS
+            uint32_t staged_cnt = 0;       // wave-uniform: bucket slots in that window
             int lc_code = 0;               // wave-uniform: child code of the last bucket served
             uint32_t lc_beg = 0, lc_cnt = 0; // (0 is an internal node: matches no leaf) + its entry
             // this lane's column of the overflow stack: entry e at spill_col[e * spill_stride]
@@ -610,31 +524,9 @@ namespace icp_dev
                             st_node += 1u;
                             st_node_lanes += (uint32_t)__builtin_popcountll(goers);
                         }
-                        uint32_t ci = 0;
-                        bool hit = true;
-                        DevNode N{};
                         if (going)
                         {
-                            ci = 31u - (uint32_t)__builtin_clz((uint32_t)node + 1u);
-                            const uint32_t cj = min(ci, (uint32_t)kPathLevels - 1u);
-                            const uint32_t tag = L.pc_tag[cj];
-                            N = L.pc_rec[cj];
-                            hit = ci < (uint32_t)kPathLevels && tag == (uint32_t)node;
-                        }
-                        const bool all_hit = __ballot(!hit) == 0ull;
-                        if (STATS && all_hit)
-                            cy_hits += 1ull;
-                        if (going)
-                        {
-                            if (!all_hit)
-                            {
-                                N = t.nodes[node];
-                                if (lane == (int)__builtin_ctzll(goers) && ci < (uint32_t)kPathLevels)
-                                {
-                                    L.pc_tag[ci] = (uint32_t)node;
-                                    L.pc_rec[ci] = N;
-                                }
-                            }
+                            const DevNode N = t.nodes[node];
                             n_int += 1u;
                             const float d2 = sq_dist(qx, qy, qz, N.cx, N.cy, N.cz);
                             const float da = __builtin_amdgcn_sqrtf(d2); // as in the general step
@@ -684,37 +576,9 @@ namespace icp_dev
                             st_node += 1u;
                             st_node_lanes += (uint32_t)__builtin_popcountll(stepping);
                         }
-                        // the node record: from the path cache in LDS when every stepping
-                        // lane finds its node there (the common case: neighbouring queries walk
-                        // the same path), else from memory, and the first stepping lane leaves
-                        // its record behind for the next visit of that tree level
-                        uint32_t ci = 0;
-                        bool hit = false;
-                        DevNode N{};
                         if (mode <= tReturn)
                         {
-                            // tag and record are read together: one LDS round trip
-                            ci = 31u - (uint32_t)__builtin_clz((uint32_t)node + 1u);
-                            const uint32_t cj = min(ci, (uint32_t)kPathLevels - 1u);
-                            const uint32_t tag = L.pc_tag[cj];
-                            N = L.pc_rec[cj];
-                            hit = ci < (uint32_t)kPathLevels && tag == (uint32_t)node;
-                        }
-                        const bool all_hit = __ballot(mode <= tReturn && !hit) == 0ull;
-                        if (STATS && all_hit)
-                            cy_hits += 1ull;
-                        if (mode <= tReturn)
-                        {
-                            if (!all_hit)
-                            {
-                                N = t.nodes[node];
-                                if (lane == (int)__builtin_ctzll(stepping) &&
-                                    ci < (uint32_t)kPathLevels)
-                                {
-                                    L.pc_tag[ci] = (uint32_t)node;
-                                    L.pc_rec[ci] = N;
-                                }
-                            }
+                            const DevNode N = t.nodes[node];
                             n_int += (mode == tDescend) ? 1u : 0u;
                             const float d2 = sq_dist(qx, qy, qz, N.cx, N.cy, N.cz);
                             const bool in_near = d2 < N.thr; // sqrtf(d2) < N.r (:147-148)
@@ -845,24 +709,37 @@ namespace icp_dev
                         const int g_all = __builtin_popcountll(grp);
                         if (g_all >= kTileMinGroup)
                         {
-                            float m;
-                            bool ok;
-                            uint32_t idx;
-                            const unsigned long long cy_t0 = now();
-                            tile_scan<STATS>(t, L, beg, cnt, grp, member, qx, qy, qz, lane, m, ok,
-                                             idx, staged, img_r2, cy_ts);
-                            staged_cnt = cnt; // meaningful while `staged` is valid
-                            cy_tile += now() - cy_t0;
-                            if (STATS)
+                            // 33..55 lanes would leave the tile half empty (one part only):
+                            // serve the first 32 as two parts, then the rest as their own group
+                            const bool split = g_all > 32 && g_all < kTileSplitBelow;
+                            const uint32_t rank_all = __builtin_amdgcn_mbcnt_hi(
+                                (uint32_t)(grp >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)grp, 0u));
+                            uint64_t rest = grp;
+                            while (rest)
                             {
-                                st_tile += 1u;
-                                st_tile_g += (uint32_t)g_all;
-                            }
-                            if (member)
-                            {
-                                rd = m;
-                                rid = beg + idx;
-                                mode = ok ? tServed : tWaitExact;
+                                const bool mem =
+                                    member && (rest == grp ? (!split || rank_all < 32u) : rank_all >= 32u);
+                                const uint64_t sub = __ballot(mem);
+                                rest &= ~sub;
+                                float m;
+                                bool unique;
+                                uint32_t idx;
+                                const unsigned long long cy_t0 = now();
+                                tile_scan(t, L, beg, cnt, sub, mem, qx, qy, qz, lane, m, unique, idx,
+                                          staged);
+                                cy_tile += now() - cy_t0;
+                                staged_cnt = min((uint32_t)kImage, beg + cnt - staged); // slots of the window in LDS
+                                if (STATS)
+                                {
+                                    st_tile += 1u;
+                                    st_tile_g += (uint32_t)__builtin_popcountll(sub);
+                                }
+                                if (mem)
+                                {
+                                    rd = m;
+                                    rid = beg + idx;
+                                    mode = unique ? tServed : tWaitExact;
+                                }
                             }
                         }
                         else if (cnt <= (uint32_t)kImage)
@@ -941,10 +818,10 @@ namespace icp_dev
                     const uint32_t in_image = rid - staged; // `staged` invalid: a huge offset
                     if (in_image < staged_cnt && staged != 0xFFFFFFFFu)
                     {
-                        // the answer is a slot of the bucket whose image is still in LDS
-                        ox = L.img[in_image];
-                        oy = L.img[kImage + in_image];
-                        oz = L.img[2 * kImage + in_image];
+                        // the answer is a slot of the bucket window that is still in LDS
+                        ox = L.bx[in_image];
+                        oy = L.by[in_image];
+                        oz = L.bz[in_image];
                     }
                     else if (rid < t.n_slots)
                     {
@@ -1045,15 +922,10 @@ namespace icp_dev
                 atomicAdd(stats + 12, cy_tile);
                 atomicAdd(stats + 13, cy_exact);
                 atomicAdd(stats + 14, cy_tail);
-                atomicAdd(stats + 15, cy_hits);
                 atomicAdd(stats + 20, (unsigned long long)__builtin_amdgcn_s_memrealtime() - rt_begin);
                 atomicAdd(stats + 21, cy_pop);
                 atomicMax(stats + 22, cy_total);
                 atomicMax(stats + 23, (unsigned long long)st_batch);
-                atomicAdd(stats + 16, cy_ts[0]);
-                atomicAdd(stats + 17, cy_ts[1]);
-                atomicAdd(stats + 18, cy_ts[2]);
-                atomicAdd(stats + 19, cy_ts[3]);
                 (void)st_tile_len;
             }
         }

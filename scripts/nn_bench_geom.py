@@ -13,7 +13,7 @@ its = int(sys.argv[4]) if len(sys.argv) > 4 else 8
 m = synth.cloud(n); mu_m = capi.mean_host(m); mc = capi.center_host(m, mu_m)
 p = synth.apply_fp32(m, synth.ground_truth(ang))
 mu_p = p.mean(0, dtype=np.float64).astype(np.float32)
-stats = os.environ.pop("ICP_HIP_TILE_STATS", None)
+
 with capi.Context() as ctx:
     ctx.build_tree(mc, cap)
     ctx.set_queries(p)
