@@ -11,6 +11,8 @@
 #include <cstring>
 #include <dlfcn.h>
 #include <limits>
+#include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <utility>
@@ -82,16 +84,121 @@ namespace
         }
     } g_rccl;
 
+    // ---- per-device pool of what a context is made of -------------------------------------
+    // The reference allocates and frees everything inside each icp() call (matrix.cu:6-17), and
+    // a caller of the drop-in does the same with a context per call.  hipMalloc / hipFree /
+    // hipStreamCreate / hipHostMalloc cost 10-40 us each (hipFree synchronises the device), which
+    // is more than a whole registration of a small cloud, so small device blocks, streams,
+    // events and the pinned state buffer return to a per-device pool instead of the driver and
+    // the next context takes them from there.  Blocks above kPoolBlockMax, or beyond
+    // kPoolTotalMax of cached bytes per device, go back to the driver as before.
+    constexpr size_t kPoolBlockMax = 8u << 20;   // largest block that is cached
+    constexpr size_t kPoolTotalMax = 64u << 20;  // cached bytes per device
+    constexpr int kPoolDevices = 64;
+
+    // A shard of fewer than kSmallBelow points is not sorted, and its loop state, NN work queue
+    // and coordinates share ONE device block [LoopState | queue | x | y | z] with a pinned image
+    // on the host for each direction: one copy up, one copy down, one synchronisation per
+    // registration (set-up, loop and download each cost a round trip of 15-25 us otherwise).
+    constexpr uint64_t kSmallBelow = 8192;
+    constexpr size_t kSmallStateBytes = 256;
+    constexpr size_t kSmallHead = 1536; // state + kQueueWords words, rounded up to 256
+    constexpr size_t kSmallBlockBytes = kSmallHead + 3 * kSmallBelow * sizeof(float);
+    constexpr size_t kStateDoubles = (sizeof(LoopState) + sizeof(double) - 1) / sizeof(double);
+    constexpr size_t kPinnedHead = 512; // 16 doubles of sums + the loop state
+    constexpr size_t kPinnedBytes = kPinnedHead + 2 * kSmallBlockBytes;
+    static_assert(sizeof(LoopState) <= kSmallStateBytes, "LoopState outgrew its slot");
+    static_assert(kSmallStateBytes + kQueueWords * sizeof(uint32_t) <= kSmallHead, "queue slot");
+    static_assert((16 + kStateDoubles) * sizeof(double) <= kPinnedHead, "pinned head");
+    struct PooledCtx
+    {
+        hipStream_t stream = nullptr;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        double* h_sums = nullptr;
+        std::vector<hipEvent_t> loop_events;
+    };
+    struct DevicePool
+    {
+        std::mutex m;
+        std::multimap<size_t, void*> blocks[kPoolDevices]; // capacity in bytes -> block
+        size_t cached[kPoolDevices] = {};
+        std::vector<PooledCtx> ctxs[kPoolDevices];
+    };
+    DevicePool& pool()
+    {
+        static DevicePool* p = new DevicePool(); // never destroyed: the HIP runtime may be gone first
+        return *p;
+    }
+    size_t pool_class(size_t bytes)
+    {
+        size_t c = 256;
+        while (c < bytes)
+            c <<= 1;
+        return c;
+    }
+    hipError_t pool_malloc(void** out, size_t bytes, size_t* cap_bytes, bool* pooled)
+    {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        *pooled = bytes <= kPoolBlockMax && dev >= 0 && dev < kPoolDevices;
+        if (!*pooled)
+        {
+            *cap_bytes = bytes;
+            return hipMalloc(out, bytes);
+        }
+        const size_t cls = pool_class(bytes);
+        *cap_bytes = cls;
+        {
+            DevicePool& P = pool();
+            std::lock_guard<std::mutex> lock(P.m);
+            auto it = P.blocks[dev].find(cls);
+            if (it != P.blocks[dev].end())
+            {
+                *out = it->second;
+                P.blocks[dev].erase(it);
+                P.cached[dev] -= cls;
+                return hipSuccess;
+            }
+        }
+        return hipMalloc(out, cls);
+    }
+    void pool_free(void* p, size_t cap_bytes, bool pooled)
+    {
+        if (!p)
+            return;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (pooled && dev >= 0 && dev < kPoolDevices)
+        {
+            DevicePool& P = pool();
+            std::lock_guard<std::mutex> lock(P.m);
+            if (P.cached[dev] + cap_bytes <= kPoolTotalMax)
+            {
+                P.blocks[dev].emplace(cap_bytes, p);
+                P.cached[dev] += cap_bytes;
+                return;
+            }
+        }
+        (void)hipFree(p);
+    }
+
     // Device array that is kept across calls: alloc(n) reuses the allocation when it is large
-    // enough (a context that is reused for the next registration allocates nothing new).
+    // enough (a context that is reused for the next registration allocates nothing new).  The
+    // owning context's device is current whenever alloc / release run, and its stream has been
+    // synchronised before a block goes back to the pool.
     template <class T>
     struct DevBuf
     {
         T* p = nullptr;
         size_t count = 0; // logical size
         size_t cap = 0;   // allocated entries
+        size_t cap_bytes = 0;
+        bool pooled = false;
+        bool borrowed = false; // p points into another DevBuf's block (never freed from here)
         hipError_t alloc(size_t n)
         {
+            if (borrowed)
+                release();
             if (n != 0 && p && n <= cap)
             {
                 count = n;
@@ -100,25 +207,38 @@ namespace
             release();
             if (n == 0)
                 return hipSuccess;
-            hipError_t e = hipMalloc((void**)&p, n * sizeof(T));
+            hipError_t e = pool_malloc((void**)&p, n * sizeof(T), &cap_bytes, &pooled);
             if (e == hipSuccess)
-                count = cap = n;
+            {
+                count = n;
+                cap = cap_bytes / sizeof(T);
+            }
             else
                 p = nullptr;
             return e;
         }
-        void adopt(T* ptr, size_t n) // take over an allocation made elsewhere
+        void adopt(T* ptr, size_t n) // take over an allocation made elsewhere (hipMalloc)
         {
             release();
             p = ptr;
             count = cap = n;
+            cap_bytes = n * sizeof(T);
+            pooled = false;
+        }
+        void borrow(T* ptr, size_t n)
+        {
+            release();
+            p = ptr;
+            count = cap = n;
+            borrowed = true;
         }
         void release()
         {
-            if (p)
-                (void)hipFree(p);
+            if (!borrowed)
+                pool_free(p, cap_bytes, pooled);
             p = nullptr;
-            count = cap = 0;
+            count = cap = cap_bytes = 0;
+            pooled = borrowed = false;
         }
     };
 } // namespace
@@ -138,6 +258,9 @@ struct icp_hip_ctx
     DevBuf<uint2> leaf_info;
     DevBuf<float> sx, sy, sz;
     DevBuf<uint32_t> srow, nrow;
+    DevBuf<unsigned char> tree_blob; // a small tree: all of the above in one block, one upload
+    std::vector<unsigned char> tree_blob_host; // its host image (kept until the next upload)
+    uint32_t n_leaves = 0;
 
     // query shard
     uint64_t n_local = 0, n_total = 0;
@@ -146,6 +269,17 @@ struct icp_hip_ctx
     DevBuf<uint32_t> row;
     DevBuf<uint32_t> perm; // sorted position -> input row (Morton order), empty when unsorted
     bool sorted = false;
+    // small shard (kSmallBelow): px/py/pz, queue and loop_state are views into `qblock`
+    bool small = false;
+    DevBuf<unsigned char> qblock;
+    unsigned char* h_up = nullptr;   // pinned image of the block on its way to the device
+    unsigned char* h_down = nullptr; // ... and as read back after a registration
+    size_t small_bytes = 0;          // bytes of the block in use (head + 3 padded arrays)
+    uint32_t small_pad = 0;          // floats per coordinate array in the block
+    bool upload_pending = false;     // h_up has not been copied to the device yet
+    bool host_points_valid = false;  // h_down holds the cloud as the last registration left it
+    bool first_sums_valid = false;   // first_sums = centroid sums of the cloud as uploaded
+    double first_sums[kApplySums] = {0.0, 0.0, 0.0, 0.0};
     DevBuf<double> partials, sums;
     double* h_sums = nullptr; // pinned, 16 doubles
 
@@ -299,9 +433,12 @@ namespace
         c->n_chunks = plan.n_chunks;
         const uint32_t k = nn_tile_stack_entries();
         c->spill_levels = c->height > k ? c->height - k : 0;
-        HIP_TRY(c, c->queue.alloc(kQueueWords));
-        // zero once: every launch of nn_tile_kernel leaves the queue zeroed behind it
-        HIP_TRY(c, hipMemsetAsync(c->queue.p, 0, kQueueWords * sizeof(uint32_t), c->stream));
+        if (!c->small) // (a small shard's queue is part of its block and arrives zeroed with it)
+        {
+            HIP_TRY(c, c->queue.alloc(kQueueWords));
+            // zero once: every launch of nn_tile_kernel leaves the queue zeroed behind it
+            HIP_TRY(c, hipMemsetAsync(c->queue.p, 0, kQueueWords * sizeof(uint32_t), c->stream));
+        }
         {
             const char* env = std::getenv("ICP_HIP_TILE_STATS");
             if (env && env[0] == '1')
@@ -310,6 +447,18 @@ namespace
         HIP_TRY(c, c->chunk_sums.alloc((size_t)c->n_chunks * kCovSums));
         HIP_TRY(c, c->spill.alloc((size_t)c->spill_levels * c->tile_grid_blocks * 256));
         c->tile_ready = true;
+        return ICP_HIP_OK;
+    }
+
+    // A small shard's block is uploaded by whoever needs it first (enqueued; every caller
+    // synchronises the stream before it returns, so h_up is free again by then).
+    int flush_queries(icp_hip_ctx* c)
+    {
+        if (!c->upload_pending)
+            return ICP_HIP_OK;
+        HIP_TRY(c, hipMemcpyAsync(c->qblock.p, c->h_up, c->small_bytes, hipMemcpyHostToDevice,
+                                  c->stream));
+        c->upload_pending = false;
         return ICP_HIP_OK;
     }
 
@@ -364,13 +513,9 @@ namespace
                          h[12], h[13], h[14], h[21],
                          h[20] ? 100.0 * (double)h[8] / (double)h[20] : 0.0, h[22], h[23]);
         }
-        // chunk sums -> <= 1024 partial rows -> the twelve sums, both in a fixed order
-        uint32_t g1 = (c->n_chunks + 63) / 64;
-        g1 = g1 > 1024 ? 1024 : g1;
-        HIP_TRY(c, launch_reduce_rows(c->chunk_sums.p, c->n_chunks, kCovSums, g1, c->partials.p,
-                                      c->stream));
-        HIP_TRY(c, launch_reduce_partials(c->partials.p, g1, kCovSums, c->sums.p, c->stream, loop,
-                                          tail));
+        // chunk sums (-> <= 1024 partial rows) -> the twelve sums, in a fixed order
+        HIP_TRY(c, launch_chunk_sums(c->chunk_sums.p, c->n_chunks, c->partials.p, c->sums.p,
+                                     c->stream, loop, tail));
         return ICP_HIP_OK;
     }
 
@@ -399,14 +544,16 @@ namespace
         {
             DevBuf<float>& a;
             DevBuf<uint32_t>&b, &d, &e;
+            hipStream_t s;
             ~Cleanup()
             {
+                (void)hipStreamSynchronize(s); // (error paths) nothing in flight uses a pooled block
                 a.release();
                 b.release();
                 d.release();
                 e.release();
             }
-        } cleanup{mm, keys, keys2, idx};
+        } cleanup{mm, keys, keys2, idx, c->stream};
         HIP_TRY(c, mm.alloc((size_t)grid * 6));
         HIP_TRY(c, keys.alloc(n));
         HIP_TRY(c, keys2.alloc(n));
@@ -429,21 +576,22 @@ namespace
                 lo[k] = std::fmin(lo[k], h[b * 6 + k]);
                 hi[k] = std::fmax(hi[k], h[b * 6 + 3 + k]);
             }
-        // one cubic cell size for all axes keeps the Z-curve isotropic
-        float ext = 0.f;
+        // one cubic cell size for all axes keeps the Z-curve isotropic.  The extent is taken in
+        // double: finite clouds whose extent overflows fp32 are legal input (the min/max kernel
+        // turns a NaN or an infinity into an infinite bound, which is what gets rejected here,
+        // like icp_host::all_finite rejects it for the clouds that are not sorted)
+        bool finite = true;
+        double ext = 0.0;
         for (int k = 0; k < 3; ++k)
-            ext = std::fmax(ext, hi[k] - lo[k]);
-        const bool finite = std::isfinite(ext) && std::isfinite(lo[0]) && std::isfinite(lo[1]) &&
-                            std::isfinite(lo[2]);
-        if (!finite) // the min/max kernel turns a NaN or infinity into an infinite extent
+        {
+            finite = finite && std::isfinite(lo[k]) && std::isfinite(hi[k]);
+            ext = std::fmax(ext, (double)hi[k] - (double)lo[k]);
+        }
+        if (!finite)
             return fail(c, ICP_HIP_ERR_ARG,
                         std::string("icp_hip_set_queries: ") + icp_host::kNonFiniteMessage);
         for (int k = 0; k < 3; ++k)
-        {
-            scale[k] = (finite && ext > 0.f) ? 1024.f / ext : 0.f;
-            if (!finite)
-                lo[k] = 0.f;
-        }
+            scale[k] = ext > 0.0 ? (float)(1024.0 / ext) : 0.f;
         HIP_TRY(c, launch_morton(c->aos.p, n, lo, scale, keys.p, idx.p, c->stream));
         HIP_TRY(c, sort_pairs_u32(keys.p, keys2.p, idx.p, c->perm.p, n, 30u, c->stream));
         HIP_TRY(c, launch_gather_soa(c->aos.p, c->perm.p, n, c->px.p, c->py.p, c->pz.p, c->stream));
@@ -462,7 +610,7 @@ namespace
             const float mu[3] = {(float)(c->h_sums[1] / n), (float)(c->h_sums[2] / n),
                                  (float)(c->h_sums[3] / n)};
             uint32_t bits = 1;
-            while (bits < 32 && (1ull << bits) < c->leaf_info.count)
+            while (bits < 32 && (1ull << bits) < c->n_leaves)
                 ++bits;
             HIP_TRY(c, launch_leaf_keys(c->tree, c->px.p, c->py.p, c->pz.p, mu, n, keys.p, idx.p,
                                         c->stream));
@@ -470,8 +618,13 @@ namespace
             struct Free
             {
                 DevBuf<uint32_t>& b;
-                ~Free() { b.release(); }
-            } free_order{order};
+                hipStream_t s;
+                ~Free()
+                {
+                    (void)hipStreamSynchronize(s);
+                    b.release();
+                }
+            } free_order{order, c->stream};
             HIP_TRY(c, order.alloc(n));
             HIP_TRY(c, sort_pairs_u32(keys.p, keys2.p, idx.p, order.p, n, bits, c->stream));
             // the matched-point arrays are free until the first pass: permute into them and swap
@@ -497,14 +650,108 @@ namespace
                         "icp_hip_set_tree: tree height " + std::to_string(t->height) +
                             " exceeds the traversal stack (" +
                             std::to_string(nn_max_depth_supported()) + " levels)");
+        if (c->has_tree) // a replaced tree's blocks go back to the pool: nothing may still use them
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->has_tree = false;
         const size_t nn = t->n_nodes, nl = t->n_leaves, ns = t->n_slots;
         const size_t slack = kSlotSlack; // bucket windows / chunks are loaded whole
+        c->n_leaves = (uint32_t)nl;
+
+        // A small tree is packed on the host into one block and uploaded with ONE copy: the ten
+        // copies, the staging arrays and the packing kernel below cost more than a whole
+        // registration of a few thousand points.
+        if (!d_sx && ns + nn <= (1u << 17))
+        {
+            auto up8 = [](size_t v) { return (v + 255) & ~(size_t)255; };
+            const size_t o_nodes = 0, o_leaf = o_nodes + up8((nn ? nn : 1) * sizeof(DevNode)),
+                         o_sx = o_leaf + up8(nl * sizeof(uint2)),
+                         o_sy = o_sx + up8((ns + slack) * 4), o_sz = o_sy + up8((ns + slack) * 4),
+                         o_srow = o_sz + up8((ns + slack) * 4), o_nrow = o_srow + up8(ns * 4),
+                         total = o_nrow + up8((nn ? nn : 1) * 4);
+            std::vector<unsigned char>& h = c->tree_blob_host;
+            try
+            {
+                h.assign(total, 0);
+            }
+            catch (const std::bad_alloc&)
+            {
+                return fail(c, ICP_HIP_ERR_NOMEM, "icp_hip_set_tree: out of host memory");
+            }
+            DevNode* hn = reinterpret_cast<DevNode*>(h.data() + o_nodes);
+            for (size_t i = 0; i < nn; ++i)
+            {
+                DevNode N;
+                N.cx = t->node_cx[i];
+                N.cy = t->node_cy[i];
+                N.cz = t->node_cz[i];
+                N.r = t->node_radius[i];
+                N.inside = t->node_inside[i];
+                N.outside = t->node_outside[i];
+                N.parent = t->node_parent[i];
+                // thr = min { s : sqrtf(s) >= r } as pack_nodes_kernel finds it (sqrtf is correctly
+                // rounded on both sides)
+                float th = 0.f;
+                if (N.r > 0.f)
+                {
+                    th = N.r * N.r;
+                    while (th > 0.f && std::sqrt(std::nextafter(th, 0.f)) >= N.r)
+                        th = std::nextafter(th, 0.f);
+                    while (std::sqrt(th) < N.r)
+                        th = std::nextafter(th, std::numeric_limits<float>::infinity());
+                }
+                N.thr = th;
+                hn[i] = N;
+            }
+            uint2* hl = reinterpret_cast<uint2*>(h.data() + o_leaf);
+            for (size_t l = 0; l < nl; ++l)
+                hl[l] = make_uint2(t->leaf_begin[l], t->leaf_count[l]);
+            auto put_slots = [&](size_t off, const float* src) {
+                float* d = reinterpret_cast<float*>(h.data() + off);
+                std::memcpy(d, src, ns * sizeof(float));
+                for (size_t k = 0; k < slack; ++k)
+                    d[ns + k] = std::numeric_limits<float>::infinity();
+            };
+            put_slots(o_sx, t->slot_x);
+            put_slots(o_sy, t->slot_y);
+            put_slots(o_sz, t->slot_z);
+            std::memcpy(h.data() + o_srow, t->slot_row, ns * sizeof(uint32_t));
+            if (nn)
+                std::memcpy(h.data() + o_nrow, t->node_row, nn * sizeof(uint32_t));
+            HIP_TRY(c, c->tree_blob.alloc(total));
+            HIP_TRY(c, hipMemcpyAsync(c->tree_blob.p, h.data(), total, hipMemcpyHostToDevice,
+                                      c->stream));
+            c->nodes.release();
+            c->leaf_info.release();
+            c->sx.release();
+            c->sy.release();
+            c->sz.release();
+            c->srow.release();
+            c->nrow.release();
+            unsigned char* b = c->tree_blob.p;
+            c->tree.nodes = reinterpret_cast<const DevNode*>(b + o_nodes);
+            c->tree.leaf_info = reinterpret_cast<const uint2*>(b + o_leaf);
+            c->tree.sx = reinterpret_cast<const float*>(b + o_sx);
+            c->tree.sy = reinterpret_cast<const float*>(b + o_sy);
+            c->tree.sz = reinterpret_cast<const float*>(b + o_sz);
+            c->tree.srow = reinterpret_cast<const uint32_t*>(b + o_srow);
+            c->tree.nrow = reinterpret_cast<const uint32_t*>(b + o_nrow);
+            c->tree.n_slots = (uint32_t)ns;
+            c->tree.n_nodes = (uint32_t)nn;
+            c->tree.root = t->root;
+            c->height = t->height;
+            c->max_leaf = t->max_leaf_count;
+            c->capacity = t->capacity;
+            c->n_tree_points = t->n_points;
+            c->has_tree = true;
+            return prepare_tile(c);
+        }
+        c->tree_blob.release();
 
         // staging for the SoA node arrays, packed into 32-byte records on the device
         DevBuf<float> f4[4];
         DevBuf<int32_t> i3[3];
         auto cleanup = [&]() {
+            (void)hipStreamSynchronize(c->stream);
             for (auto& b : f4)
                 b.release();
             for (auto& b : i3)
@@ -607,17 +854,20 @@ namespace
                                       c->stream));
             return ICP_HIP_OK;
         }
-        const uint32_t g_st = stream_grid(n);
+        const uint32_t g_st = c->small ? 1u : stream_grid(n);
+        const int tail = sharded ? kTailNone : kTailFinish;
         Mat34 unused{};
         if (ev)
             HIP_TRY(c, hipEventRecord(ev[2], c->stream));
+        // (a small shard: one workgroup, which also sums and runs the loop step)
         HIP_TRY(c, launch_apply_error(c->px.p, c->py.p, c->pz.p, c->yx.p, c->yy.p, c->yz.p, unused,
-                                      zero, n, g_st, c->partials.p, c->loop_state, c->stream));
+                                      zero, n, g_st, c->partials.p, c->loop_state, c->stream,
+                                      c->small ? c->sums.p + kApplyAt : nullptr, tail));
         if (ev)
             HIP_TRY(c, hipEventRecord(ev[3], c->stream));
-        HIP_TRY(c, launch_reduce_partials(c->partials.p, g_st, kApplySums, c->sums.p + kApplyAt,
-                                          c->stream, c->loop_state,
-                                          sharded ? kTailNone : kTailFinish));
+        if (!c->small)
+            HIP_TRY(c, launch_reduce_partials(c->partials.p, g_st, kApplySums,
+                                              c->sums.p + kApplyAt, c->stream, c->loop_state, tail));
         return ICP_HIP_OK;
     }
 
@@ -628,6 +878,16 @@ namespace
         if (n == 0)
         {
             HIP_TRY(c, hipMemsetAsync(c->sums.p + kApplyAt, 0, sizeof(double) * kApplySums,
+                                      c->stream));
+            return ICP_HIP_OK;
+        }
+        if (c->small && c->first_sums_valid)
+        {
+            // summed on the host while the block was packed
+            for (int k = 0; k < kApplySums; ++k)
+                c->h_sums[kApplyAt + k] = c->first_sums[k];
+            HIP_TRY(c, hipMemcpyAsync(c->sums.p + kApplyAt, c->h_sums + kApplyAt,
+                                      sizeof(double) * kApplySums, hipMemcpyHostToDevice,
                                       c->stream));
             return ICP_HIP_OK;
         }
@@ -668,12 +928,31 @@ namespace
         const bool sharded = c->comm != nullptr;
         int rc;
         // first mean(p) (icp.cc:114); T = I, error = +inf (:101-104)
-        if ((rc = enqueue_first_sums(c)) != ICP_HIP_OK)
-            return rc;
-        if (sharded && (rc = rccl_allreduce(c, kApplyAt, kApplySums)) != ICP_HIP_OK)
-            return rc;
-        HIP_TRY(c, launch_loop_init(c->loop_state, c->sums.p + kApplyAt, mu_m, threshold, cap_iters,
-                                    (double)c->n_total, c->stream));
+        if (c->small && c->first_sums_valid && !sharded)
+        {
+            // the same step on the host, into the image of the block: it goes up with the cloud
+            LoopState* hs = reinterpret_cast<LoopState*>(c->h_up);
+            loop_init_step(hs, c->first_sums, mu_m, threshold, cap_iters, (double)c->n_total);
+            if (c->upload_pending)
+                rc = flush_queries(c);
+            else
+                rc = hipMemcpyAsync(c->loop_state, hs, sizeof(LoopState), hipMemcpyHostToDevice,
+                                    c->stream) == hipSuccess
+                         ? ICP_HIP_OK
+                         : fail(c, ICP_HIP_ERR_HIP, "icp_hip_run: upload of the loop state failed");
+            if (rc != ICP_HIP_OK)
+                return rc;
+        }
+        else
+        {
+            if ((rc = flush_queries(c)) != ICP_HIP_OK || (rc = enqueue_first_sums(c)) != ICP_HIP_OK)
+                return rc;
+            if (sharded && (rc = rccl_allreduce(c, kApplyAt, kApplySums)) != ICP_HIP_OK)
+                return rc;
+            HIP_TRY(c, launch_loop_init(c->loop_state, c->sums.p + kApplyAt, mu_m, threshold,
+                                        cap_iters, (double)c->n_total, c->stream));
+        }
+        c->first_sums_valid = false; // the loop moves the cloud
         const uint32_t slots_cap = cap_iters == 0 ? 0u : cap_iters + (sharded ? 1u : 0u);
         uint32_t slots = 0, it_done = 0, block = 1;
         std::vector<float> slot_nn, slot_ap; // kernel times by slot (slot i holds iteration i)
@@ -691,9 +970,12 @@ namespace
                 if ((rc = enqueue_slot(c, c->phase_timers ? c->loop_events.data() + 4 * s
                                                           : nullptr)) != ICP_HIP_OK)
                     return rc;
-            HIP_TRY(c, hipMemcpyAsync(c->h_loop, c->loop_state, sizeof(LoopState),
+            // (a small shard: the whole block, i.e. the state and the cloud as moved so far)
+            HIP_TRY(c, hipMemcpyAsync(c->h_loop, c->loop_state,
+                                      c->small ? c->small_bytes : sizeof(LoopState),
                                       hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
+            c->host_points_valid = c->small;
             const LoopState& st = *c->h_loop;
             for (uint32_t s = 0; s < B; ++s)
             {
@@ -754,12 +1036,15 @@ namespace
         c->nn_trace.clear();
         LoopState st{};
         int rc;
+        c->host_points_valid = false;
         // first mean(p) (icp.cc:114); T = I, error = +inf (:101-104)
-        if ((rc = enqueue_first_sums(c)) != ICP_HIP_OK ||
+        if ((rc = flush_queries(c)) != ICP_HIP_OK || (rc = enqueue_first_sums(c)) != ICP_HIP_OK ||
             (rc = sums_to_host(c, kApplyAt, kApplySums)) != ICP_HIP_OK ||
             (rc = host_allreduce(c, kApplyAt, kApplySums)) != ICP_HIP_OK)
             return rc;
         loop_init_step(&st, c->h_sums + kApplyAt, mu_m, threshold, cap_iters, (double)c->n_total);
+        c->first_sums_valid = false; // the loop moves the cloud
+        const uint32_t g_ap = c->small ? 1u : g_st;
 
         float nn_ms = 0.f, ap_ms = 0.f; // kernel times of the iteration whose error is pending
         auto finished = [&](uint32_t it_before) {
@@ -815,11 +1100,13 @@ namespace
                 std::memcpy(M.m, st.Tn, sizeof M.m);
                 HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
                 HIP_TRY(c, launch_apply_error(c->px.p, c->py.p, c->pz.p, c->yx.p, c->yy.p, c->yz.p,
-                                              M, st.mu_m, n, g_st, c->partials.p, nullptr,
-                                              c->stream));
+                                              M, st.mu_m, n, g_ap, c->partials.p, nullptr,
+                                              c->stream,
+                                              c->small ? c->sums.p + kApplyAt : nullptr));
                 HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-                HIP_TRY(c, launch_reduce_partials(c->partials.p, g_st, kApplySums,
-                                                  c->sums.p + kApplyAt, c->stream));
+                if (!c->small)
+                    HIP_TRY(c, launch_reduce_partials(c->partials.p, g_st, kApplySums,
+                                                      c->sums.p + kApplyAt, c->stream));
             }
             else
                 HIP_TRY(c, hipMemsetAsync(c->sums.p + kApplyAt, 0, sizeof(double) * kApplySums,
@@ -988,18 +1275,40 @@ extern "C"
             icp_hip_destroy(c);
             return rc;
         };
-        if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess)
-            return bail(e, "hipStreamCreate");
-        if ((e = hipEventCreate(&c->ev0)) != hipSuccess)
-            return bail(e, "hipEventCreate");
-        if ((e = hipEventCreate(&c->ev1)) != hipSuccess)
-            return bail(e, "hipEventCreate");
-        // 16 doubles of sums + the device-resident loop's state, on the device and pinned
-        constexpr size_t kStateDoubles = (sizeof(LoopState) + sizeof(double) - 1) / sizeof(double);
-        if ((e = hipHostMalloc((void**)&c->h_sums, (16 + kStateDoubles) * sizeof(double),
-                               hipHostMallocDefault)) != hipSuccess)
-            return bail(e, "hipHostMalloc");
+        bool from_pool = false;
+        if (device_id < kPoolDevices)
+        {
+            DevicePool& P = pool();
+            std::lock_guard<std::mutex> lock(P.m);
+            if (!P.ctxs[device_id].empty())
+            {
+                PooledCtx r = std::move(P.ctxs[device_id].back());
+                P.ctxs[device_id].pop_back();
+                c->stream = r.stream;
+                c->ev0 = r.ev0;
+                c->ev1 = r.ev1;
+                c->h_sums = r.h_sums;
+                c->loop_events = std::move(r.loop_events);
+                from_pool = true;
+            }
+        }
+        if (!from_pool)
+        {
+            if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess)
+                return bail(e, "hipStreamCreate");
+            if ((e = hipEventCreate(&c->ev0)) != hipSuccess)
+                return bail(e, "hipEventCreate");
+            if ((e = hipEventCreate(&c->ev1)) != hipSuccess)
+                return bail(e, "hipEventCreate");
+            // 16 doubles of sums + the device-resident loop's state, on the device and pinned
+            // (+ the two pinned images of a small shard's block)
+            if ((e = hipHostMalloc((void**)&c->h_sums, kPinnedBytes, hipHostMallocDefault)) !=
+                hipSuccess)
+                return bail(e, "hipHostMalloc");
+        }
         c->h_loop = reinterpret_cast<LoopState*>(c->h_sums + 16);
+        c->h_up = reinterpret_cast<unsigned char*>(c->h_sums) + kPinnedHead;
+        c->h_down = c->h_up + kSmallBlockBytes;
         if ((e = c->sums.alloc(16 + kStateDoubles)) != hipSuccess)
             return bail(e, "hipMalloc(sums)");
         c->loop_state = reinterpret_cast<LoopState*>(c->sums.p + 16);
@@ -1072,6 +1381,27 @@ extern "C"
         c->stats.release();
         c->partials.release();
         c->sums.release();
+        c->tree_blob.release();
+        c->qblock.release();
+        if (c->stream && c->ev0 && c->ev1 && c->h_sums && c->device < kPoolDevices)
+        {
+            // the stream is idle (synchronised above): the next context on this device takes it
+            PooledCtx r;
+            r.stream = c->stream;
+            r.ev0 = c->ev0;
+            r.ev1 = c->ev1;
+            r.h_sums = c->h_sums;
+            r.loop_events = std::move(c->loop_events);
+            DevicePool& P = pool();
+            std::lock_guard<std::mutex> lock(P.m);
+            if (P.ctxs[c->device].size() < 8)
+            {
+                P.ctxs[c->device].push_back(std::move(r));
+                delete c;
+                return;
+            }
+            c->loop_events = std::move(r.loop_events);
+        }
         if (c->h_sums)
             (void)hipHostFree(c->h_sums);
         for (hipEvent_t ev : c->loop_events)
@@ -1190,7 +1520,7 @@ extern "C"
         out->n_points = c->n_tree_points;
         out->n_slots = c->tree.n_slots;
         out->n_nodes = c->tree.n_nodes;
-        out->n_leaves = (uint32_t)c->leaf_info.count;
+        out->n_leaves = c->n_leaves;
         out->height = c->height;
         out->capacity = c->capacity;
         out->max_leaf_count = c->max_leaf;
@@ -1210,7 +1540,7 @@ extern "C"
         try
         {
             T = new icp_host::FlatTreeOwner();
-            const size_t nn = c->tree.n_nodes, nl = c->leaf_info.count, ns = c->tree.n_slots;
+            const size_t nn = c->tree.n_nodes, nl = c->n_leaves, ns = c->tree.n_slots;
             std::vector<DevNode> nodes(nn);
             std::vector<uint2> li(nl);
             T->node_row.resize(nn);
@@ -1222,19 +1552,19 @@ extern "C"
                 return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream)
                              : hipSuccess;
             };
-            hipError_t e = down(nodes.data(), c->nodes.p, nn * sizeof(DevNode));
+            hipError_t e = down(nodes.data(), c->tree.nodes, nn * sizeof(DevNode));
             if (e == hipSuccess)
-                e = down(T->node_row.data(), c->nrow.p, nn * sizeof(uint32_t));
+                e = down(T->node_row.data(), c->tree.nrow, nn * sizeof(uint32_t));
             if (e == hipSuccess)
-                e = down(li.data(), c->leaf_info.p, nl * sizeof(uint2));
+                e = down(li.data(), c->tree.leaf_info, nl * sizeof(uint2));
             if (e == hipSuccess)
-                e = down(T->slot_x.data(), c->sx.p, ns * sizeof(float));
+                e = down(T->slot_x.data(), c->tree.sx, ns * sizeof(float));
             if (e == hipSuccess)
-                e = down(T->slot_y.data(), c->sy.p, ns * sizeof(float));
+                e = down(T->slot_y.data(), c->tree.sy, ns * sizeof(float));
             if (e == hipSuccess)
-                e = down(T->slot_z.data(), c->sz.p, ns * sizeof(float));
+                e = down(T->slot_z.data(), c->tree.sz, ns * sizeof(float));
             if (e == hipSuccess)
-                e = down(T->slot_row.data(), c->srow.p, ns * sizeof(uint32_t));
+                e = down(T->slot_row.data(), c->tree.srow, ns * sizeof(uint32_t));
             if (e == hipSuccess)
                 e = hipStreamSynchronize(c->stream);
             if (e != hipSuccess)
@@ -1299,24 +1629,81 @@ extern "C"
             return fail(c, ICP_HIP_ERR_ARG, "icp_hip_set_queries: shard larger than 2^31-1 points");
         DeviceGuard g(c->device);
         c->has_queries = false;
+        c->upload_pending = c->host_points_valid = c->first_sums_valid = false;
         const size_t n = n_local ? n_local : 1;
-        HIP_TRY(c, c->px.alloc(n));
-        HIP_TRY(c, c->py.alloc(n));
-        HIP_TRY(c, c->pz.alloc(n));
         HIP_TRY(c, c->yx.alloc(n));
         HIP_TRY(c, c->yy.alloc(n));
         HIP_TRY(c, c->yz.alloc(n));
-        HIP_TRY(c, c->aos.alloc(3 * n));
         HIP_TRY(c, c->row.alloc(n));
         HIP_TRY(c, c->dist.alloc(n));
         HIP_TRY(c, c->partials.alloc((size_t)kNnMaxBlocks * kCovSums));
         c->sorted = false;
+        c->small = n_local >= 1 && n_local < kSmallBelow;
+        if (c->small)
+        {
+            // [LoopState | queue | x | y | z]: packed on the host (with the finiteness check and
+            // the first centroid sums, in double, in input order), uploaded by the first user
+            const uint32_t pad = ((uint32_t)n_local + 63u) & ~63u;
+            HIP_TRY(c, c->qblock.alloc(kSmallBlockBytes));
+            float* d = reinterpret_cast<float*>(c->qblock.p + kSmallHead);
+            c->px.borrow(d, n_local);
+            c->py.borrow(d + pad, n_local);
+            c->pz.borrow(d + 2 * (size_t)pad, n_local);
+            c->queue.borrow(reinterpret_cast<uint32_t*>(c->qblock.p + kSmallStateBytes),
+                            kQueueWords);
+            c->loop_state = reinterpret_cast<LoopState*>(c->qblock.p);
+            c->h_loop = reinterpret_cast<LoopState*>(c->h_down);
+            c->small_pad = pad;
+            c->small_bytes = kSmallHead + 3 * (size_t)pad * sizeof(float);
+            std::memset(c->h_up, 0, kSmallHead);
+            float* hx = reinterpret_cast<float*>(c->h_up + kSmallHead);
+            float *hy = hx + pad, *hz = hy + pad;
+            double sx = 0.0, sy = 0.0, sz = 0.0;
+            for (size_t i = 0; i < n_local; ++i)
+            {
+                const float x = xyz_aos[3 * i], y = xyz_aos[3 * i + 1], z = xyz_aos[3 * i + 2];
+                hx[i] = x;
+                hy[i] = y;
+                hz[i] = z;
+                sx += (double)x;
+                sy += (double)y;
+                sz += (double)z;
+            }
+            for (size_t i = n_local; i < pad; ++i)
+                hx[i] = hy[i] = hz[i] = 0.f;
+            // (a NaN or an infinity anywhere makes a sum non-finite; finite sums of fp32 values
+            // cannot overflow a double)
+            if (!std::isfinite(sx) || !std::isfinite(sy) || !std::isfinite(sz))
+                return fail(c, ICP_HIP_ERR_ARG,
+                            std::string("icp_hip_set_queries: ") + icp_host::kNonFiniteMessage);
+            c->first_sums[0] = 0.0;
+            c->first_sums[1] = sx;
+            c->first_sums[2] = sy;
+            c->first_sums[3] = sz;
+            c->first_sums_valid = true;
+            c->upload_pending = true;
+            c->n_local = n_local;
+            c->n_total = n_total;
+            c->has_queries = true;
+            c->timing = icp_hip_timing{};
+            return prepare_tile(c);
+        }
+        c->loop_state = reinterpret_cast<LoopState*>(c->sums.p + 16);
+        c->h_loop = reinterpret_cast<LoopState*>(c->h_sums + 16);
+        c->qblock.release();
+        HIP_TRY(c, c->px.alloc(n));
+        HIP_TRY(c, c->py.alloc(n));
+        HIP_TRY(c, c->pz.alloc(n));
+        HIP_TRY(c, c->aos.alloc(3 * n));
+        if (c->queue.borrowed)
+            c->queue.release();
         if (n_local)
         {
             HIP_TRY(c, hipMemcpyAsync(c->aos.p, xyz_aos, 3 * n_local * sizeof(float),
                                       hipMemcpyHostToDevice, c->stream));
             const char* env = std::getenv("ICP_HIP_SORT_QUERIES");
-            const bool want_sort = !(env && env[0] == '0') && n_local >= 1024;
+            // (below ~8k points the two sorts of the set-up cost more than they save)
+            const bool want_sort = !(env && env[0] == '0') && n_local >= kSmallBelow;
             if (!want_sort && !icp_host::all_finite(xyz_aos, 3 * n_local))
                 return fail(c, ICP_HIP_ERR_ARG,
                             std::string("icp_hip_set_queries: ") + icp_host::kNonFiniteMessage);
@@ -1354,12 +1741,15 @@ extern "C"
         NnLaunch a = make_nn(c, mu_p, true, true, true, true);
         float ms = 0.f;
         {
-            int rc = nn_pass(c, a, &ms);
+            int rc = flush_queries(c);
+            if (rc == ICP_HIP_OK)
+                rc = nn_pass(c, a, &ms);
             if (rc != ICP_HIP_OK)
                 return rc;
         }
         if (xyz_out)
         {
+            HIP_TRY(c, c->aos.alloc(3ull * n));
             if (c->sorted)
                 HIP_TRY(c, launch_scatter_aos(c->yx.p, c->yy.p, c->yz.p, c->perm.p, n, c->aos.p,
                                               c->stream));
@@ -1527,6 +1917,25 @@ extern "C"
             return fail(c, ICP_HIP_ERR_ARG, "icp_hip_get_points: xyz_aos is NULL");
         DeviceGuard g(c->device);
         const uint32_t n = (uint32_t)c->n_local;
+        if (c->small && c->host_points_valid)
+        {
+            // the last registration brought the block back with its state: nothing to wait for
+            const float* hx = reinterpret_cast<const float*>(c->h_down + kSmallHead);
+            const float *hy = hx + c->small_pad, *hz = hy + c->small_pad;
+            for (uint32_t i = 0; i < n; ++i)
+            {
+                xyz_aos[3 * (size_t)i] = hx[i];
+                xyz_aos[3 * (size_t)i + 1] = hy[i];
+                xyz_aos[3 * (size_t)i + 2] = hz[i];
+            }
+            return ICP_HIP_OK;
+        }
+        {
+            int rc = flush_queries(c);
+            if (rc != ICP_HIP_OK)
+                return rc;
+        }
+        HIP_TRY(c, c->aos.alloc(3ull * n));
         if (c->sorted)
             HIP_TRY(c, launch_scatter_aos(c->px.p, c->py.p, c->pz.p, c->perm.p, n, c->aos.p,
                                           c->stream));

@@ -146,11 +146,19 @@ namespace icp_dev
     // out[b][k] = sum of rows [b*rows_per_block, ...) of rows[n_rows][K], fixed order; K <= 16
     hipError_t launch_reduce_rows(const double* rows, uint32_t n_rows, int K, uint32_t grid,
                                   double* out, hipStream_t s);
-    // `loop` null: T and mu_m are the arguments; else they are loop->Tn / loop->mu_m
+    // `loop` null: T and mu_m are the arguments; else they are loop->Tn / loop->mu_m.
+    // `out` not null (grid must be 1): the kApplySums sums go straight to out, without a
+    // reduce_partials launch, followed by the loop step `tail` (kTailFinish or kTailNone)
     hipError_t launch_apply_error(float* px, float* py, float* pz, const float* yx, const float* yy,
                                   const float* yz, const Mat34& T, const float mu_m[3], uint32_t n,
-                                  uint32_t grid, double* partials, const LoopState* loop,
-                                  hipStream_t s);
+                                  uint32_t grid, double* partials, LoopState* loop, hipStream_t s,
+                                  double* out = nullptr, int tail = 0);
+    // the per-chunk sums of nn_tile_kernel -> the kCovSums sums in `out`, in a fixed order: one
+    // launch up to kChunksOneStage chunks, two (through `partials`, <= 1024 rows) above
+    constexpr uint32_t kChunksOneStage = 512;
+    hipError_t launch_chunk_sums(const double* chunk_sums, uint32_t n_chunks, double* partials,
+                                 double* out, hipStream_t s, LoopState* loop = nullptr,
+                                 int tail = 0);
     // loop.hip: single-thread steps of the device-resident loop
     hipError_t launch_loop_init(LoopState* st, const double* sums, const float mu_m[3],
                                 float threshold, uint32_t max_iters, double n_total, hipStream_t s);

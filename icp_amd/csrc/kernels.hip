@@ -252,8 +252,8 @@ namespace icp_dev
         apply_error_kernel(float* __restrict__ px, float* __restrict__ py, float* __restrict__ pz,
                            const float* __restrict__ yx, const float* __restrict__ yy,
                            const float* __restrict__ yz, Mat34 T, float mmx, float mmy, float mmz,
-                           uint32_t n, double* __restrict__ partials,
-                           const LoopState* __restrict__ loop)
+                           uint32_t n, double* __restrict__ partials, LoopState* loop,
+                           double* out, int tail)
     {
         __shared__ double s_red[kWavesPerBlock * kApplySums];
         if (loop)
@@ -295,7 +295,17 @@ namespace icp_dev
             acc[2] += (double)ny;
             acc[3] += (double)nz;
         }
-        block_store_partials<kApplySums>(acc, s_red, partials);
+        if (!out)
+        {
+            block_store_partials<kApplySums>(acc, s_red, partials);
+            return;
+        }
+        // a grid of ONE workgroup (small clouds): its partial sums are the sums, and the loop step
+        // that consumes them runs here instead of in reduce_partials_kernel
+        block_store_partials<kApplySums>(acc, s_red, out);
+        __syncthreads();
+        if (threadIdx.x == 0 && loop && tail == kTailFinish)
+            loop_finish_step(loop, out);
     }
 
     __global__ void __launch_bounds__(kBlock)
@@ -480,12 +490,27 @@ namespace icp_dev
 
     hipError_t launch_apply_error(float* px, float* py, float* pz, const float* yx, const float* yy,
                                   const float* yz, const Mat34& T, const float mu_m[3], uint32_t n,
-                                  uint32_t grid, double* partials, const LoopState* loop,
-                                  hipStream_t s)
+                                  uint32_t grid, double* partials, LoopState* loop,
+                                  hipStream_t s, double* out, int tail)
     {
+        if (out && grid != 1)
+            return hipErrorInvalidValue;
         hipLaunchKernelGGL(apply_error_kernel, dim3(grid), dim3(kBlock), 0, s, px, py, pz, yx, yy,
-                           yz, T, mu_m[0], mu_m[1], mu_m[2], n, partials, loop);
+                           yz, T, mu_m[0], mu_m[1], mu_m[2], n, partials, loop, out, tail);
         return hipGetLastError();
+    }
+
+    hipError_t launch_chunk_sums(const double* chunk_sums, uint32_t n_chunks, double* partials,
+                                 double* out, hipStream_t s, LoopState* loop, int tail)
+    {
+        if (n_chunks <= kChunksOneStage)
+            return launch_reduce_partials(chunk_sums, n_chunks, kCovSums, out, s, loop, tail);
+        uint32_t g1 = (n_chunks + 63) / 64;
+        g1 = g1 > 1024 ? 1024 : g1;
+        hipError_t e = launch_reduce_rows(chunk_sums, n_chunks, kCovSums, g1, partials, s);
+        if (e != hipSuccess)
+            return e;
+        return launch_reduce_partials(partials, g1, kCovSums, out, s, loop, tail);
     }
 
     hipError_t launch_sum_points(const float* px, const float* py, const float* pz, uint32_t n,

@@ -1041,13 +1041,7 @@ namespace icp_dev
         if ((e = launch_nn_tile(a, q, s)) != hipSuccess)
             return e;
         if (sums_out)
-        {
-            uint32_t g1 = (p.n_chunks + 63) / 64;
-            g1 = g1 > 1024 ? 1024 : g1;
-            if ((e = launch_reduce_rows(chunk_sums, p.n_chunks, kCovSums, g1, partials, s)) != hipSuccess)
-                return e;
-            e = launch_reduce_partials(partials, g1, kCovSums, sums_out, s);
-        }
+            e = launch_chunk_sums(chunk_sums, p.n_chunks, partials, sums_out, s);
         return e;
     }
 

@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -72,6 +73,7 @@ namespace icp_host
             std::vector<TmpLeaf> leaves;
             std::mutex lock;
             bool degenerate = false;
+            bool oom = false; // an allocation failed inside the task region (no exception may leave it)
 
             static constexpr uint64_t kTaskMin = 1u << 14;   // spawn tasks above this size
             static constexpr uint64_t kLoopPar = 1u << 20;   // parallelise inner loops above this
@@ -92,7 +94,15 @@ namespace icp_host
                 if (size < capacity)
                 {
                     std::lock_guard<std::mutex> g(lock);
-                    leaves.push_back({lo, (uint32_t)size});
+                    try
+                    {
+                        leaves.push_back({lo, (uint32_t)size});
+                    }
+                    catch (const std::bad_alloc&)
+                    {
+                        oom = true;
+                        return ~0;
+                    }
                     return ~(int32_t)(leaves.size() - 1);
                 }
                 const uint32_t crow = perm[hi - 1];
@@ -186,7 +196,15 @@ namespace icp_host
                 }
                 TmpNode nd{cx, cy, cz, std::sqrt(r2), in_code, out_code, crow};
                 std::lock_guard<std::mutex> g(lock);
-                nodes.push_back(nd);
+                try
+                {
+                    nodes.push_back(nd);
+                }
+                catch (const std::bad_alloc&)
+                {
+                    oom = true;
+                    return ~0;
+                }
                 return (int32_t)(nodes.size() - 1);
             }
         };
@@ -242,6 +260,11 @@ namespace icp_host
 #pragma omp single
         root = b.build(0, n);
 
+        if (b.oom)
+        {
+            err = "icp_hip_tree_build: out of host memory";
+            return ICP_HIP_ERR_NOMEM;
+        }
         if (b.degenerate)
         {
             err = "icp_hip_tree_build: degenerate cloud: a vantage-point split left one side empty "
@@ -256,7 +279,9 @@ namespace icp_host
         // ---- renumber: internal nodes breadth-first, leaves left to right ----
         const uint32_t n_nodes = (uint32_t)b.nodes.size();
         const uint32_t n_leaves = (uint32_t)b.leaves.size();
-        auto* T = new FlatTreeOwner();
+        // (held by a unique_ptr until it is handed out: a later resize may throw)
+        std::unique_ptr<FlatTreeOwner> owner(new FlatTreeOwner());
+        FlatTreeOwner* const T = owner.get();
         T->node_cx.resize(n_nodes);
         T->node_cy.resize(n_nodes);
         T->node_cz.resize(n_nodes);
@@ -379,7 +404,7 @@ namespace icp_host
         v.max_leaf_count = max_leaf;
         v.root = recode(root);
         T->sync_view();
-        *out = T;
+        *out = owner.release();
         return ICP_HIP_OK;
     }
 

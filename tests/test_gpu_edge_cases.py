@@ -99,3 +99,22 @@ def test_non_finite_coordinates_are_refused(bad, n):
         assert e.value.status == 1
         T, new_p, it, err = ctx.icp(m, m, 5, 1e-5, 32)   # the context is still good
         assert it == 1 and err <= 1e-5
+
+
+@pytest.mark.parametrize("n", [100, 5000])
+def test_finite_cloud_with_an_fp32_overflowing_extent_is_accepted(n):
+    """Finite coordinates whose extent overflows fp32 (hi - lo = inf) are legal input at every
+    size: the set-up order of the larger shards must not mistake them for non-finite ones."""
+    from icp_amd import capi, synth
+    m = synth.cloud(2000, seed=3)
+    p = synth.cloud(n, seed=4)
+    p[0] = [3.0e38, -3.0e38, 3.0e38]
+    p[1] = [-3.0e38, 3.0e38, -3.0e38]
+    mu_m = capi.mean_host(m)
+    tree = capi.FlatTree(capi.center_host(m, mu_m), 32)
+    with capi.Context() as ctx:
+        ctx.set_tree(tree)
+        ctx.set_queries(p)   # must not raise
+        out = ctx.nn(np.zeros(3, np.float32), want=("row",))
+    assert out["row"].shape == (n,) and (out["row"] < len(m)).all()
+    tree.close()
