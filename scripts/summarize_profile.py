@@ -34,4 +34,4 @@ for k in nn:
 if a.bench_json:
     j = json.loads(open(a.bench_json).read().strip().splitlines()[-1])
     print(f"bench.py (same command) roofline.avg_launch_ms = {j['roofline']['avg_launch_ms']} ms, "
-          f"achieved {j['roofline']['achieved']} GB/s, frac {j['roofline']['frac']}")
+          f"{j['roofline'].get('bound')}: achieved {j['roofline']['achieved']} {j['roofline'].get('unit')}, frac {j['roofline']['frac']}")
