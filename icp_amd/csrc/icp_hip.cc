@@ -431,6 +431,16 @@ namespace
         c->tile_grid_blocks = plan.grid_blocks;
         c->chunk_batches = plan.chunk_batches;
         c->n_chunks = plan.n_chunks;
+        if (const char* cbe = std::getenv("ICP_HIP_CHUNK_BATCHES")) // experiments only
+        {
+            const uint32_t cb = (uint32_t)std::atoi(cbe);
+            if (cb >= 1 && cb <= 64)
+            {
+                const uint64_t batches = (c->n_local + plan.batch_queries - 1) / plan.batch_queries;
+                c->chunk_batches = cb;
+                c->n_chunks = (uint32_t)((batches + cb - 1) / cb);
+            }
+        }
         const uint32_t k = nn_tile_stack_entries();
         c->spill_levels = c->height > k ? c->height - k : 0;
         if (!c->small) // (a small shard's queue is part of its block and arrives zeroed with it)

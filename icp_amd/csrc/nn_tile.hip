@@ -5,11 +5,15 @@
 // (libcpu/libcpu/point-3d.cc:212-236).  What differs is how the work is laid on the machine, for
 // a shard that is stored in a spatially coherent order (sort.hip):
 //
-//  * persistent grid; the shard is cut into chunks of 1..8 consecutive 64-query batches and every
+//  * persistent grid; the shard is cut into chunks of 1..2 consecutive 64-query batches and every
 //    wave pulls chunks from a queue.  There is one queue head per XCD group (blockIdx % 8,
 //    round-robin dispatch) over one eighth of the shard each, so the waves of an XCD work on
-//    neighbouring chunks at the same time (a bucket is fetched from HBM about once and then
-//    lives in that XCD's L2); a group that runs dry steals from the others (load balance);
+//    neighbouring chunks AT THE SAME TIME: the four batches that end in one bucket stage it
+//    within microseconds of each other and three of them find it in that XCD's L2.  (A line
+//    lives ~7 us in a 4 MiB L2 at this kernel's 0.5 GB/ms per XCD; with chunks of 8 batches a
+//    wave came back to a bucket 30 us later and every staging was a miss: 9.1 GB fetched per
+//    aligned 64M launch against 2.3 GB now, profiles/r02b.)  A group that runs dry steals
+//    from the others (load balance);
 //  * every chunk writes its own twelve fp64 sums and two small kernels add the chunks in a fixed
 //    order: the result does not depend on which wave ran which chunk (bitwise reproducible);
 //  * the traversal stack holds only the near-side answers of the levels whose far side is being
@@ -458,8 +462,17 @@ namespace icp_dev
                 cy_pop += now() - cy_p0;
                 if (!have)
                     break;
-                if (lane < kCovSums)
-                    L.sums[lane] = 0.0;
+                // (once per chunk: `lane_c` is opaque to the compiler so that the zero and the
+                // address of this lane's chunk sum are made here, not kept in registers -- they
+                // were what spilled to scratch -- across the whole kernel)
+                uint32_t lane_c = (uint32_t)lane;
+                asm volatile("" : "+v"(lane_c));
+                if (lane_c < (uint32_t)kCovSums)
+                {
+                    uint32_t z;
+                    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+                    *reinterpret_cast<uint2*>(&L.sums[lane_c]) = make_uint2(z, z); // +0.0
+                }
                 const uint32_t b_begin = chunk * chunk_batches;
                 const uint32_t b_end = min(b_begin + chunk_batches, n_batches);
             for (uint32_t b = b_begin; b < b_end; ++b)
@@ -698,7 +711,10 @@ namespace icp_dev
                         st_leafph += 1u;
                     while (pend)
                     {
-                        const int l = (int)__builtin_ctzll(pend);
+                        // the bucket whose image is still in LDS first (the batch before ended
+                        // in it, more often than not), then by lane
+                        const uint64_t kept = __ballot(mode == tWaitLeaf && lbeg == staged) & pend;
+                        const int l = (int)__builtin_ctzll(kept ? kept : pend);
                         const uint32_t beg = readlane_u(lbeg, l), cnt = readlane_u(lcnt, l);
                         lc_code = __builtin_amdgcn_readlane(prev, l);
                         lc_beg = beg;
@@ -887,8 +903,8 @@ namespace icp_dev
                 }
                 cy_tail += now() - cy_e0;
             }
-                if (chunk_sums && lane < kCovSums)
-                    chunk_sums[(size_t)chunk * kCovSums + lane] = L.sums[lane];
+                if (chunk_sums && lane_c < (uint32_t)kCovSums)
+                    chunk_sums[(size_t)chunk * kCovSums + lane_c] = L.sums[lane_c];
             }
             // the last workgroup to get here leaves the queue heads zero for the next launch
             __syncthreads();
@@ -956,9 +972,11 @@ namespace icp_dev
         if (g > max_blocks)
             g = max_blocks;
         p.grid_blocks = (uint32_t)(g < 1 ? 1 : g);
-        // chunks: ~8 per wave for load balance, at most 8 batches each
+        // chunks: at most 2 batches each (measured at 64M: 1 -> 7.64, 2 -> 7.55, 4 -> 7.62,
+        // 8 -> 7.87 ms per iteration; the L2 reason is at the top of the file), 1 when the shard
+        // has fewer than ~16 batches per wave
         const uint64_t cb = batches / ((uint64_t)p.grid_blocks * 4 * 8);
-        p.chunk_batches = (uint32_t)(cb < 1 ? 1 : (cb > 8 ? 8 : cb));
+        p.chunk_batches = (uint32_t)(cb < 1 ? 1 : (cb > 2 ? 2 : cb));
         p.n_chunks = (uint32_t)((batches + p.chunk_batches - 1) / p.chunk_batches);
         return p;
     }
