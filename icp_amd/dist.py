@@ -1,8 +1,9 @@
 """One process per GPU: shard bounds and the per-iteration all-reduce of the small sums.
 
 The path shards over the points to move (each is an independent NN query); the only exchange is
-one all-reduce of 12 doubles after the NN pass and one of 4 doubles after the apply pass, per
-iteration (include/icp_hip.h: icp_hip_set_allreduce / icp_hip_comm_init_rank).  The reference has
+ONE all-reduce of 16 doubles per iteration: the NN pass' nine covariance sums and three work
+counters together with the error and the centroid sums of the apply pass of the iteration before
+(include/icp_hip.h: icp_hip_set_allreduce / icp_hip_comm_init_rank).  The reference has
 no counterpart (it is single-device); the parity target is the single-GPU result.
 """
 from __future__ import annotations

@@ -200,13 +200,25 @@ int icp_hip_nn_noalloc(icp_hip_ctx* ctx, const float* d_px, const float* d_py, c
                        float* d_yx, float* d_yy, float* d_yz, double* d_sums_out, void* stream);
 
 /* All-reduce hook for runs sharded over several contexts: sum `count` doubles in place over all
- * shards (host memory).  Return 0 on success.  Leave unset (or set RCCL below) for one GPU. */
+ * shards (host memory).  Return 0 on success.  Leave unset (or set RCCL below) for one GPU.
+ * icp_hip_run calls it once with 4 doubles (the centroid sums of the cloud as uploaded) and then
+ * ONCE PER ITERATION with 16: [0..8] sum q (x) y and [9..11] the work counters of this
+ * iteration's NN pass, [12] the error and [13..15] the centroid sums of the apply pass of the
+ * iteration before (zeros in the first call).  The loop condition of an iteration is therefore
+ * known one call later: a run of k iterations makes k + 1 calls of 16. */
 typedef int (*icp_hip_allreduce_fn)(double* values, int count, void* user);
 int icp_hip_set_allreduce(icp_hip_ctx* ctx, icp_hip_allreduce_fn fn, void* user);
 
 /* RCCL communicator over xGMI, one rank per context.  unique_id is the 128-byte ncclUniqueId
- * made by icp_hip_comm_unique_id on rank 0 and distributed by the caller.  When set, the
- * per-iteration sums are all-reduced on the device on the context's stream. */
+ * made by icp_hip_comm_unique_id on rank 0 and distributed by the caller.  When set, the same
+ * 16 doubles are all-reduced on the device, on the context's stream, one ncclAllReduce per
+ * iteration, and the loop stays on the device on every rank (iterations enqueued in blocks of
+ * 1, 2, 4, 8, 8, .. like the single-GPU loop; every rank reads the same state after the
+ * all-reduce and so enqueues the same collectives; a rank whose shard is empty takes part with
+ * zeros).  What would make one rank choose another loop (ICP_HIP_LOOP=host, ICP_HIP_NN_KERNEL=deep,
+ * ICP_HIP_TILE_STATS, icp_hip_set_allreduce) is rejected with ICP_HIP_ERR_ARG by icp_hip_run.
+ * Verified with one rank on one GPU (bit-equal to the run without a communicator) and, for the
+ * protocol, with two gloo ranks on the CPU; more than one RCCL rank has not run on hardware. */
 int icp_hip_comm_unique_id(void* unique_id_out, size_t size /* >= 128 */);
 int icp_hip_comm_init_rank(icp_hip_ctx* ctx, int n_ranks, int rank, const void* unique_id,
                            size_t size);
