@@ -58,7 +58,7 @@ namespace icp_dev
         constexpr int kStackK = 4;  // LDS stack entries per lane
         constexpr int kImage = 256; // bucket slots staged per window
         constexpr int kGroups = kImage / 4; // float4 groups of the image; group kGroups is +inf
-        constexpr int kTileMinGroup = 3; // fewer lanes on a bucket: whole-wave scan per lane
+        constexpr int kTileMinGroup = 4; // fewer lanes on a bucket: whole-wave scan per lane
         constexpr int kTileSplitBelow = 56; // 33..55 lanes: scan as 32 + rest (see the leaf phase)
 
         enum : int
