@@ -1456,11 +1456,10 @@ extern "C"
         c->has_tree = false;
         // A small cloud is built by the host builder (same tree, bit for bit) and uploaded: the
         // level-by-level device build costs ~0.1 ms of launches per level whatever the size.
-        // (measured on the 48k-point horse: host 0.77 ms against 1.16 ms at capacity 256, where
-        // the tree has 8 levels; level at capacity 32, 11 levels)
-        constexpr uint64_t kHostBuildBelow = 8192, kHostBuildShallowBelow = 131072;
-        const bool shallow = n < kHostBuildShallowBelow && n / capacity <= 256;
-        if (c->tree_build_on == 2 || (c->tree_build_on == 0 && (n < kHostBuildBelow || shallow)))
+        // (the 48k-point horse at capacity 256, 8 levels: host 0.8 ms against 1.2 ms, but with 16
+        // OpenMP threads woken per call and a noisy wall time; not worth it)
+        constexpr uint64_t kHostBuildBelow = 8192;
+        if (c->tree_build_on == 2 || (c->tree_build_on == 0 && n < kHostBuildBelow))
         {
             icp_flat_tree* t = nullptr;
             int rc = icp_hip_tree_build(xyz_centered, n, capacity, &t);

@@ -5,7 +5,10 @@
 // file by oracle/Makefile into oracle/_ref/libicp_ref.so.  It is used to (1) validate the
 // restatement in oracle/icp_oracle.cc bit for bit and (2) generate the golden fixtures under
 // tests/golden/ (tests/golden/make_golden.py).  /root/reference does not exist on the GPU
-// box, so nothing that runs there may depend on this library.
+// box: the built library travels there like the product's own .so files, and the only thing on
+// the box that may load it is the `cpu_baseline` leg of bench.py (kind "reference", timed beside
+// the GPU path, never part of it), which falls back to the port when the file is absent; no test
+// marked gpu, smoke() or product code depends on it.
 //
 // libcpu/libcpu/icp.cc is NOT built: it needs Eigen 3.3.7 (<Eigen/Dense>, icp.cc:3), which the
 // reference fetches by URL and is absent offline.
