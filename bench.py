@@ -292,8 +292,10 @@ def main():
                 "traffic": None, "hbm": None, "counters_from": None,
                 "fp32_no_fma": {"achieved": round(flop_ach, 2), "peak": round(flop_peak, 2),
                                 "unit": "TFLOP/s", "frac": round(flop_ach / flop_peak, 4),
-                                "note": "8 flops per distance (3 sub, 3 mul, 2 add; never "
-                                        "contracted: the answers must round like the reference's)"},
+                                "note": "8 flops per distance in the reference's arithmetic "
+                                        "(3 sub, 3 mul, 2 add, never contracted); the scan's "
+                                        "filter spends 6 operations with FMA and re-checks the "
+                                        "winner with the reference's"},
                 "algorithmic_GBs": round(bytes_per_launch / avg_s / 1e9, 1),
                 "algorithmic_bytes_per_launch": round(bytes_per_launch),
                 "bytes_per_query": round(alg_bytes_all / max(1.0, tm["queries"]), 1),

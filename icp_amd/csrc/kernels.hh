@@ -187,8 +187,11 @@ namespace icp_dev
                              hipStream_t s);
     hipError_t launch_morton(const float* aos, uint32_t n, const float lo[3], const float scale[3],
                              uint32_t* keys, uint32_t* idx, hipStream_t s);
+    // temp null (or too small): temporary storage is allocated, the stream waited for, and freed
     hipError_t sort_pairs_u32(const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* idx_in,
-                              uint32_t* idx_out, uint32_t n, uint32_t bits, hipStream_t s);
+                              uint32_t* idx_out, uint32_t n, uint32_t bits, hipStream_t s,
+                              void* temp = nullptr, size_t temp_bytes = 0);
+    hipError_t sort_pairs_u32_temp_bytes(uint32_t n, uint32_t bits, size_t* bytes);
     hipError_t launch_leaf_keys(const DevTree& t, const float* px, const float* py, const float* pz,
                                 const float mu[3], uint32_t n, uint32_t* keys, uint32_t* idx,
                                 hipStream_t s);

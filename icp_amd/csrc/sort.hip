@@ -199,14 +199,26 @@ namespace icp_dev
 
     // Stable LSD radix sort of (key, idx) pairs on the low `bits` bits of the keys.  Set-up path: allocates and frees
     // rocPRIM's temporary storage.
+    hipError_t sort_pairs_u32_temp_bytes(uint32_t n, uint32_t bits, size_t* bytes)
+    {
+        *bytes = 0;
+        return rocprim::radix_sort_pairs(nullptr, *bytes, (const uint32_t*)nullptr,
+                                         (uint32_t*)nullptr, (const uint32_t*)nullptr,
+                                         (uint32_t*)nullptr, (size_t)n, 0u, bits, (hipStream_t)0);
+    }
+
     hipError_t sort_pairs_u32(const uint32_t* keys_in, uint32_t* keys_out, const uint32_t* idx_in,
-                              uint32_t* idx_out, uint32_t n, uint32_t bits, hipStream_t s)
+                              uint32_t* idx_out, uint32_t n, uint32_t bits, hipStream_t s,
+                              void* temp, size_t temp_bytes)
     {
         size_t bytes = 0;
         hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, keys_in, keys_out, idx_in, idx_out,
                                                  (size_t)n, 0u, bits, s);
         if (e != hipSuccess)
             return e;
+        if (temp && temp_bytes >= bytes) // the caller's temporary storage: enqueued, nothing waited for
+            return rocprim::radix_sort_pairs(temp, bytes, keys_in, keys_out, idx_in, idx_out,
+                                             (size_t)n, 0u, bits, s);
         void* tmp = nullptr;
         if ((e = hipMalloc(&tmp, bytes ? bytes : 16)) != hipSuccess)
             return e;

@@ -1,0 +1,79 @@
+"""The second ordering pass of a long registration (icp_hip.cc, maybe_resort): once the clouds are
+aligned the shard is put in leaf order again.  The order a shard is stored in is invisible to the
+caller: rows, distances and the moved cloud come back in the caller's order (the reference
+evaluates queries in input order, libcpu/libcpu/vp-tree.cc:182-184), NN answers are the oracle's
+bit for bit before and after the pass, and the registration is the one without the pass up to the
+order of the fp64 sums."""
+import numpy as np
+import pytest
+
+from conftest import bits
+
+pytestmark = pytest.mark.gpu
+
+N = 700_000
+
+
+@pytest.fixture(scope="module")
+def world():
+    from icp_amd import capi, synth
+    m = synth.cloud(N, seed=11)
+    mu_m = capi.mean_host(m)
+    mc = capi.center_host(m, mu_m)
+    rng = np.random.default_rng(3)
+    order = rng.permutation(N)            # the caller's order is not a spatial one
+    p = synth.apply_fp32(m, synth.ground_truth(1.0))[order]
+    return dict(m=m, mu_m=mu_m, mc=mc, p=p, order=order)
+
+
+def _run(monkeypatch, resort, world, iters):
+    from icp_amd import capi
+    if resort:
+        monkeypatch.delenv("ICP_HIP_RESORT", raising=False)
+    else:
+        monkeypatch.setenv("ICP_HIP_RESORT", "0")
+    with capi.Context() as ctx:
+        ctx.build_tree(world["mc"], 256)
+        ctx.set_queries(world["p"])
+        T, it, err = ctx.run(world["mu_m"], iters, 0.0)
+        moved = ctx.get_points()
+        trace = ctx.nn_trace()
+        mu = capi.mean_host(moved)
+        out = ctx.nn(mu)
+        dev = ctx.get_tree()
+    return dict(T=T, it=it, err=err, moved=moved, trace=trace, mu=mu, out=out, tree=dev)
+
+
+def test_resort_is_invisible_to_the_caller(monkeypatch, world, oracle):
+    a = _run(monkeypatch, True, world, 16)
+    b = _run(monkeypatch, False, world, 16)
+    assert a["it"] == b["it"] == 16
+    # the same registration up to the summation order of the fp64 sums
+    assert np.abs(a["T"] - b["T"]).max() <= 2e-7
+    assert np.abs(a["moved"] - b["moved"]).max() <= 1e-6
+    # the moved cloud is in the caller's order: row i is the image of input row i
+    m = world["m"][world["order"]]
+    assert np.abs(a["moved"] - m).max() < 1e-4
+    # a pass after the re-ordering: rows / distances / coordinates in the caller's order, and the
+    # oracle's bit for bit on the same queries
+    q = (a["moved"] - a["mu"]).astype(np.float32)
+    sub = np.arange(0, N, 7)
+    want = oracle.tree_closest(oracle.tree_from_flat(a["tree"]), q[sub])
+    assert (a["out"]["row"][sub] == want["row"]).all()
+    assert (bits(a["out"]["dist"][sub]) == bits(want["dist"])).all()
+    assert (bits(a["out"]["xyz"][sub]) == bits(want["xyz"])).all()
+    assert (a["out"]["row"] == world["order"]).mean() > 0.999  # each point finds its own pre-image
+    # the pass did happen, and it paid: later NN passes are faster than without it
+    assert np.median(a["trace"][-4:]) < np.median(b["trace"][-4:])
+    a["tree"].close()
+    b["tree"].close()
+
+
+def test_short_or_unfinished_registrations_are_left_alone(monkeypatch, world):
+    """Fewer than four iterations to go, or still far from aligned: no second pass (the run is
+    then bit-identical to the run with the pass switched off)."""
+    a = _run(monkeypatch, True, world, 3)
+    b = _run(monkeypatch, False, world, 3)
+    assert (bits(a["T"]) == bits(b["T"])).all() and (bits(a["moved"]) == bits(b["moved"])).all()
+    a["tree"].close()
+    b["tree"].close()
