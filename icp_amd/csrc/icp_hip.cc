@@ -666,9 +666,13 @@ namespace
     // re-ordered, 3 ms for the pass itself).  Decided on the host where it reads the loop state
     // anyway -- after iterations 1, 3, 7, 15, 23, .. (the ends of the enqueue blocks), in both
     // loops, from state bits that are the same in both -- and at most once per registration:
-    // when the last iteration moved no point by more than 2 % of the point spacing and at least
-    // four more iterations may follow.  Which order the shard is stored in never changes an
-    // answer; it changes the order of the fp64 sums, like any other change of the shard's order.
+    // when the last iteration applied moved no point by more than 2 % of the point spacing and
+    // at least four more iterations may follow.  Which order the shard is stored in never
+    // changes an answer; it changes the order of the fp64 sums, like any other change of the
+    // shard's order.  With an RCCL communicator every rank reads the same state after the
+    // all-reduce and takes the same decision about its own shard (the pass involves no other
+    // rank); there the last iteration applied is one ahead of the last one finished, which is
+    // why the test is on `started`.
     constexpr uint64_t kResortMinPoints = 1u << 19;
     bool at_block_end(uint32_t it)
     {
@@ -682,9 +686,9 @@ namespace
     }
     int maybe_resort(icp_hip_ctx* c, const LoopState& st)
     {
-        if (c->resorted || !c->sorted || !c->leaf_ordered || c->comm || c->allreduce ||
-            c->n_local < kResortMinPoints || st.done || st.it == 0 ||
-            st.max_iters - st.it < 4u || !at_block_end(st.it) || !(c->q_extent > 0.0))
+        if (c->resorted || !c->sorted || !c->leaf_ordered || c->allreduce ||
+            c->n_local < kResortMinPoints || st.done || st.started == 0 ||
+            st.max_iters - st.started < 4u || !at_block_end(st.started) || !(c->q_extent > 0.0))
             return ICP_HIP_OK;
         {
             const char* env = std::getenv("ICP_HIP_RESORT");

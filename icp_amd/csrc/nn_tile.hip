@@ -309,38 +309,30 @@ namespace icp_dev
         }
 
         // Whole-wave scan of one bucket of <= 256 slots for ONE query (arguments wave-uniform):
-        // the cheaper form when only one or two lanes wait on the bucket.  All chunk loads are
-        // issued before the first use.  Returns the SQUARED distance of the reference's answer
-        // (its sqrt is the reference's distance) and the answer's slot.
+        // the cheaper form when only a few lanes wait on the bucket.  Lane l holds the float4
+        // group l of the bucket (slots 4l .. 4l+3: three 16-byte loads per lane; a bucket starts
+        // at a multiple of 16 slots and its padding is +inf, so a group never reaches into the
+        // next bucket and padding slots evaluate to +inf).  Returns the SQUARED distance of the
+        // reference's answer (its sqrt is the reference's distance) and the answer's slot.
         __device__ __forceinline__ void coop_scan(const DevTree& t, float bx, float by, float bz,
                                                   uint32_t beg, uint32_t cnt, int lane, float& m_out,
                                                   uint32_t& win_out)
         {
             const float kInf = __int_as_float(0x7f800000);
-            const uint32_t last = beg + cnt - 1u;
-            float x[4], y[4], z[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
+            const uint32_t s0 = 4u * (uint32_t)lane;
+            float s[4] = {kInf, kInf, kInf, kInf};
+            if (s0 < cnt)
             {
-                x[c] = y[c] = z[c] = kInf;
-                if ((uint32_t)(c * kWave) < cnt) // wave-uniform
-                {
-                    const uint32_t j = min(beg + (uint32_t)(c * kWave + lane), last);
-                    x[c] = t.sx[j];
-                    y[c] = t.sy[j];
-                    z[c] = t.sz[j];
-                }
+                const size_t o = (size_t)beg + s0;
+                const float4 X = *reinterpret_cast<const float4*>(t.sx + o);
+                const float4 Y = *reinterpret_cast<const float4*>(t.sy + o);
+                const float4 Z = *reinterpret_cast<const float4*>(t.sz + o);
+                s[0] = sq_dist(bx, by, bz, X.x, Y.x, Z.x);
+                s[1] = sq_dist(bx, by, bz, X.y, Y.y, Z.y);
+                s[2] = sq_dist(bx, by, bz, X.z, Y.z, Z.z);
+                s[3] = sq_dist(bx, by, bz, X.w, Y.w, Z.w);
             }
-            float s[4];
-            float smin = kInf;
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-            {
-                const float d2 = sq_dist(bx, by, bz, x[c], y[c], z[c]);
-                s[c] = ((uint32_t)(c * kWave + lane) < cnt) ? d2 : kInf;
-                smin = fminf(smin, s[c]);
-            }
-            const float m = wave_min_nonneg(smin);
+            const float m = wave_min_nonneg(fminf(fminf(s[0], s[1]), fminf(s[2], s[3])));
             // candidates: every slot within 4 ulps of the minimum (a superset of the slots whose
             // sqrt equals sqrt(m)); exactly one candidate is the common case
             const float near = __uint_as_float(__float_as_uint(m) + 4u);
@@ -360,17 +352,14 @@ namespace icp_dev
                 for (int c = 0; c < 4; ++c)
                     h[c] = __ballot(s[c] <= hi);
             }
-            uint32_t win = beg; // a NaN-poisoned bucket keeps slot 0, like the reference's scan
-            if (h[0])
-                win = beg + (uint32_t)__builtin_ctzll(h[0]);
-            else if (h[1])
-                win = beg + 64u + (uint32_t)__builtin_ctzll(h[1]);
-            else if (h[2])
-                win = beg + 128u + (uint32_t)__builtin_ctzll(h[2]);
-            else if (h[3])
-                win = beg + 192u + (uint32_t)__builtin_ctzll(h[3]);
+            // first slot among the hits: slot = 4 * lane + c (scalar arithmetic)
+            uint32_t first = 0xFFFFFFFFu; // a NaN-poisoned bucket keeps slot 0, like the reference's scan
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (h[c])
+                    first = min(first, 4u * (uint32_t)__builtin_ctzll(h[c]) + (uint32_t)c);
             m_out = m;
-            win_out = win;
+            win_out = beg + (first == 0xFFFFFFFFu ? 0u : first);
         }
 
     } // namespace

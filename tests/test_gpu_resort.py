@@ -77,3 +77,24 @@ def test_short_or_unfinished_registrations_are_left_alone(monkeypatch, world):
     assert (bits(a["T"]) == bits(b["T"])).all() and (bits(a["moved"]) == bits(b["moved"])).all()
     a["tree"].close()
     b["tree"].close()
+
+
+def test_resort_under_a_communicator_equals_the_plain_run(monkeypatch, world):
+    """With an RCCL communicator (one rank here) the loop condition is known one slot late, and
+    the second ordering pass is decided from `started`, not `it`: the same iteration triggers it
+    as without a communicator, so the two runs are bit-identical."""
+    from icp_amd import capi
+    monkeypatch.delenv("ICP_HIP_RESORT", raising=False)
+    res = []
+    for use_comm in (False, True):
+        with capi.Context() as ctx:
+            ctx.build_tree(world["mc"], 256)
+            if use_comm:
+                ctx.comm_init_rank(1, 0, capi.Context.comm_unique_id())
+            ctx.set_queries(world["p"])
+            errs = []
+            T, it, err = ctx.run(world["mu_m"], 16, 0.0, progress=lambda i, mx, e: errs.append(e))
+            res.append((T.copy(), it, err, errs, ctx.get_points(), ctx.nn_trace()))
+    assert res[0][1] == res[1][1] == 16 and res[0][3] == res[1][3]
+    assert (bits(res[0][0]) == bits(res[1][0])).all()
+    assert (bits(res[0][4]) == bits(res[1][4])).all()
