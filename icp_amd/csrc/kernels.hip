@@ -270,30 +270,55 @@ namespace icp_dev
             mmz = loop->mu_m[2];
         }
         double acc[kApplySums] = {0.0, 0.0, 0.0, 0.0};
-        for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
-        {
-            const float x = px[i], y = py[i], z = pz[i];
-            const float nx = __fadd_rn(
+        auto one = [&](float x, float y, float z, float ux, float uy, float uz, float& nx, float& ny,
+                       float& nz) {
+            nx = __fadd_rn(
                 __fadd_rn(__fadd_rn(__fmul_rn(x, T.m[0]), __fmul_rn(y, T.m[1])), __fmul_rn(z, T.m[2])),
                 T.m[3]);
-            const float ny = __fadd_rn(
+            ny = __fadd_rn(
                 __fadd_rn(__fadd_rn(__fmul_rn(x, T.m[4]), __fmul_rn(y, T.m[5])), __fmul_rn(z, T.m[6])),
                 T.m[7]);
-            const float nz = __fadd_rn(
+            nz = __fadd_rn(
                 __fadd_rn(__fadd_rn(__fmul_rn(x, T.m[8]), __fmul_rn(y, T.m[9])), __fmul_rn(z, T.m[10])),
                 T.m[11]);
-            px[i] = nx;
-            py[i] = ny;
-            pz[i] = nz;
-            const float ex = __fsub_rn(__fadd_rn(yx[i], mmx), nx);
-            const float ey = __fsub_rn(__fadd_rn(yy[i], mmy), ny);
-            const float ez = __fsub_rn(__fadd_rn(yz[i], mmz), nz);
+            const float ex = __fsub_rn(__fadd_rn(ux, mmx), nx);
+            const float ey = __fsub_rn(__fadd_rn(uy, mmy), ny);
+            const float ez = __fsub_rn(__fadd_rn(uz, mmz), nz);
             const float e =
                 __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(ez, ez));
             acc[0] += (double)e;
             acc[1] += (double)nx;
             acc[2] += (double)ny;
             acc[3] += (double)nz;
+        };
+        // four points per lane and step (16-byte loads and stores; the arrays are 256-byte
+        // aligned), the last n % 4 points one by one
+        const uint32_t n4 = n >> 2;
+        for (uint32_t g = blockIdx.x * kBlock + threadIdx.x; g < n4; g += gridDim.x * kBlock)
+        {
+            const float4 X = reinterpret_cast<const float4*>(px)[g];
+            const float4 Y = reinterpret_cast<const float4*>(py)[g];
+            const float4 Z = reinterpret_cast<const float4*>(pz)[g];
+            const float4 U = reinterpret_cast<const float4*>(yx)[g];
+            const float4 V = reinterpret_cast<const float4*>(yy)[g];
+            const float4 W = reinterpret_cast<const float4*>(yz)[g];
+            float4 A, B, C;
+            one(X.x, Y.x, Z.x, U.x, V.x, W.x, A.x, B.x, C.x);
+            one(X.y, Y.y, Z.y, U.y, V.y, W.y, A.y, B.y, C.y);
+            one(X.z, Y.z, Z.z, U.z, V.z, W.z, A.z, B.z, C.z);
+            one(X.w, Y.w, Z.w, U.w, V.w, W.w, A.w, B.w, C.w);
+            reinterpret_cast<float4*>(px)[g] = A;
+            reinterpret_cast<float4*>(py)[g] = B;
+            reinterpret_cast<float4*>(pz)[g] = C;
+        }
+        if (blockIdx.x == 0 && threadIdx.x < (n & 3u))
+        {
+            const uint32_t i = (n4 << 2) + threadIdx.x;
+            float nx, ny, nz;
+            one(px[i], py[i], pz[i], yx[i], yy[i], yz[i], nx, ny, nz);
+            px[i] = nx;
+            py[i] = ny;
+            pz[i] = nz;
         }
         if (!out)
         {
