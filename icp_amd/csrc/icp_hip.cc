@@ -1552,8 +1552,13 @@ extern "C"
         struct Free
         {
             DevBuf<float>& b;
-            ~Free() { b.release(); }
-        } free_cloud{cloud};
+            hipStream_t s;
+            ~Free()
+            {
+                (void)hipStreamSynchronize(s); // nothing in flight reads a block that is pooled
+                b.release();
+            }
+        } free_cloud{cloud, c->stream};
         HIP_TRY(c, hipMemcpyAsync(cloud.p, xyz_centered, 3 * n * sizeof(float),
                                   hipMemcpyHostToDevice, c->stream));
         BuiltTree bt;
