@@ -57,9 +57,13 @@ class Hip:
         return out
 
     def stream(self) -> int:
-        s = C.c_void_p()
-        self.ok(self.rt.hipStreamCreate(C.byref(s)))
-        return s.value
+        # one stream for the whole module: the first launch on a new stream makes the runtime
+        # allocate that queue's own buffers (8 MB), which is not the entry point's doing
+        if getattr(self, "_stream", None) is None:
+            s = C.c_void_p()
+            self.ok(self.rt.hipStreamCreate(C.byref(s)))
+            self._stream = s.value
+        return self._stream
 
     def sync(self, stream: int):
         self.ok(self.rt.hipStreamSynchronize(C.c_void_p(stream)))
@@ -138,6 +142,33 @@ def test_noalloc_matches_icp_hip_nn_twice_in_a_row(hip, oracle):
         got = _run_noalloc(hip, ctx, p, mu_p, stream)
         ref = oracle.tree_closest(oracle.tree_build(cap, mc), oracle.subtract(p, mu_p))
         assert (got["row"] == ref["row"]).all() and (bits(got["dist"]) == bits(ref["dist"])).all()
+
+
+def test_covariance_sums_against_the_reference_golden(hip, clouds):
+    """find_covariance (libcpu/libcpu/point-3d.cc:212-236) on the GPU, H itself: the nine sums the
+    NN kernel returns for horse_tr1 against the covariance the compiled reference computed for the
+    same clouds (golden; sequential fp32 sums, hence the drift bound) and against the exact sum of
+    the same fp32 products."""
+    import os
+    from conftest import GOLDEN
+    from icp_amd import capi
+    g = np.load(os.path.join(GOLDEN, "nn_horse_tr1_cap32.npz"))
+    m, p = clouds["horse_ref"], clouds["horse_tr1"]
+    mu_m = capi.mean_host(m)
+    mc = capi.center_host(m, mu_m)
+    stream = hip.stream()
+    with capi.Context() as ctx:
+        ctx.build_tree(mc, 32)
+        got = _run_noalloc(hip, ctx, p, g["mu_p"], stream)
+    assert (got["row"] == g["row"]).all()
+    H = got["sums"][:9]
+    q = (p - g["mu_p"]).astype(np.float32)
+    y = mc[g["row"]]
+    exact = (q[:, :, None] * y[:, None, :]).astype(np.float32).astype(np.float64).sum(0).reshape(9)
+    assert np.allclose(H, exact, rtol=1e-12, atol=1e-9)
+    assert np.abs(H - g["cov"].astype(np.float64).reshape(9)).max() < 2e-3  # fp32 sequential drift
+    assert got["sums"][9] == float(g["n_int"].astype(np.int64).sum())
+    assert got["sums"][10] == float(g["n_pts"].astype(np.int64).sum())
 
 
 def test_noalloc_outputs_are_optional_and_limits_are_enforced(hip):
