@@ -289,6 +289,7 @@ struct icp_hip_ctx
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint32_t tile_blocks = 0;   // resident nn_tile_kernel workgroups on this device (multiple of 8)
+    uint32_t cus = 0;           // compute units (0 when tile_blocks is not a whole number per CU)
     bool force_deep = false;    // ICP_HIP_NN_KERNEL=deep: always run nn_cov_kernel
     int tree_build_on = 0;      // ICP_HIP_TREE_BUILD: 0 auto (by size), 1 device, 2 host
     // nn_tile_kernel work queue / per-chunk sums / overflow stack (sized by prepare_tile)
@@ -430,7 +431,8 @@ namespace
         if (!c->has_tree || !c->has_queries || c->n_local == 0)
             return ICP_HIP_OK;
         const char* env = std::getenv("ICP_HIP_BATCH_QUERIES");
-        const TilePlan plan = plan_tile(c->n_local, c->tile_blocks, env ? (uint32_t)std::atoi(env) : 0u);
+        const TilePlan plan = plan_tile(c->n_local, c->tile_blocks,
+                                        env ? (uint32_t)std::atoi(env) : 0u, c->cus);
         c->batch_queries = plan.batch_queries;
         c->tile_grid_blocks = plan.grid_blocks;
         c->chunk_batches = plan.chunk_batches;
@@ -1418,6 +1420,7 @@ extern "C"
             if (blocks > kNnMaxBlocks)
                 blocks = kNnMaxBlocks;
             c->tile_blocks = (uint32_t)blocks;
+            c->cus = (cus > 0 && blocks == (uint64_t)per_cu * (uint64_t)cus) ? (uint32_t)cus : 0u;
             const char* env = std::getenv("ICP_HIP_NN_KERNEL");
             c->force_deep = env && std::strcmp(env, "deep") == 0;
             const char* tb = std::getenv("ICP_HIP_TREE_BUILD");

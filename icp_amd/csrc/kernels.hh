@@ -120,7 +120,10 @@ namespace icp_dev
     {
         uint32_t batch_queries, grid_blocks, chunk_batches, n_chunks;
     };
-    TilePlan plan_tile(uint64_t n, uint32_t max_blocks, uint32_t forced_batch_queries);
+    // cus (0 = not known): compute units of the device; lets the plan leave workgroup slots of a
+    // CU empty when the shard has too few batches to keep every resident wave busy
+    TilePlan plan_tile(uint64_t n, uint32_t max_blocks, uint32_t forced_batch_queries,
+                       uint32_t cus = 0);
 
     // ---- the pass that allocates nothing (icp_hip_nn_noalloc) ----
     // Its work queue, per-chunk sums, partial rows and overflow stack live in a file-scope
@@ -129,7 +132,7 @@ namespace icp_dev
     constexpr uint32_t kNoAllocMaxQueries = 1u << 20; // queries per call
     constexpr uint32_t kNoAllocMaxBlocks = 256;       // grid: one workgroup per CU
     constexpr uint32_t kNoAllocMaxChunks = 16384;     // plan_tile(n <= 2^20, 256 blocks) stays below
-    constexpr uint32_t kNoAllocSpillLevels = 28;      // tree height <= 28 + the on-chip entries
+    constexpr uint32_t kNoAllocSpillLevels = 30;      // tree height <= 30 + the on-chip entries
     constexpr size_t kNoAllocScratchBytes =
         4096                                                        // queue heads
         + (size_t)kNoAllocMaxChunks * kCovSums * 8                    // per-chunk sums

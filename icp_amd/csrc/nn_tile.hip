@@ -55,7 +55,7 @@ namespace icp_dev
 {
     namespace
     {
-        constexpr int kStackK = 4;  // LDS stack entries per lane
+        constexpr int kStackK = 2;  // LDS stack entries per lane
         constexpr int kImage = 256; // bucket slots staged per window
         constexpr int kGroups = kImage / 4; // float4 groups of the image; group kGroups is +inf
         constexpr int kTileMinGroup = 4; // fewer lanes on a bucket: whole-wave scan per lane
@@ -365,7 +365,7 @@ namespace icp_dev
     } // namespace
 
         template <bool STATS>
-        __global__ void __launch_bounds__(kBlock, 6) // 6 workgroups per CU (LDS 6 x 24.7 KiB, <= 80 VGPRs)
+        __global__ void __launch_bounds__(kBlock, 7) // 7 workgroups per CU (LDS 7 x 20.7 KiB, <= 72 VGPRs)
             nn_tile_kernel(DevTree t, const float* __restrict__ px, const float* __restrict__ py,
                            const float* __restrict__ pz, float mux, float muy, float muz, uint32_t n,
                            float* __restrict__ yx, float* __restrict__ yy, float* __restrict__ yz,
@@ -941,7 +941,7 @@ namespace icp_dev
 
     uint32_t nn_tile_stack_entries() { return kStackK; }
 
-    TilePlan plan_tile(uint64_t n, uint32_t max_blocks, uint32_t forced_bq)
+    TilePlan plan_tile(uint64_t n, uint32_t max_blocks, uint32_t forced_bq, uint32_t cus)
     {
         // queries per batch: 64 (one per lane) when that fills every resident wave slot; a
         // smaller shard is cut into narrower batches (32/16/8/4 queries per wave) so that all
@@ -960,6 +960,19 @@ namespace icp_dev
         uint64_t g = (batches + 3) / 4;
         if (g > max_blocks)
             g = max_blocks;
+        // A shard that fills the chip only a few batches deep runs faster with fewer, faster
+        // waves: the pass ends when the slowest wave has done its ceil(batches / waves) batches,
+        // and a wave's speed falls with every other wave on its SIMD.  Measured (ms per NN pass,
+        // aligned, 4 / 5 / 6 / 7 workgroups per CU): 1M points 0.138 / 0.148 / 0.158 / 0.168,
+        // 2M 0.213 (5) / 0.221 / 0.230, 4M 0.346 (5) / 0.340 / 0.344, 64M: 7 is 4 % faster than 6.
+        // So: the most workgroups per CU that still leave ~4 batches per wave, at least 4.
+        if (cus != 0 && g == max_blocks && max_blocks % cus == 0 && max_blocks / cus > 4)
+        {
+            uint32_t per_cu = max_blocks / cus;
+            while (per_cu > 4 && batches * 10 < (uint64_t)38 * 4 * cus * per_cu)
+                --per_cu;
+            g = (uint64_t)cus * per_cu;
+        }
         p.grid_blocks = (uint32_t)(g < 1 ? 1 : g);
         // chunks: at most 2 batches each (measured at 64M: 1 -> 7.64, 2 -> 7.55, 4 -> 7.62,
         // 8 -> 7.87 ms per iteration; the L2 reason is at the top of the file), 1 when the shard

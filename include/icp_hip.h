@@ -190,7 +190,7 @@ int icp_hip_nn(icp_hip_ctx* ctx, const float mu_p[3], uint32_t* row_out, float* 
  *   - everything is enqueued on `stream` (a hipStream_t, NULL = the default stream) and nothing
  *     is waited for;
  *   - the call makes no hipMalloc / hipFree / allocating library call: the kernel's work queue,
- *     per-chunk sums and overflow stack live in a static device array of 16.4 MB that every GPU
+ *     per-chunk sums and overflow stack live in a static device array of 17.4 MB that every GPU
  *     the library runs on holds until the process ends.  Hence the limits: n <= 1,048,576
  *     queries per call (ICP_HIP_ERR_ARG beyond) and tree height <= 32 (ICP_HIP_ERR_DEPTH), and a
  *     grid of one workgroup per CU.  All calls on one GPU share that array: calls that overlap
