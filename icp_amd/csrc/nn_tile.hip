@@ -17,7 +17,7 @@
 //  * every chunk writes its own twelve fp64 sums and two small kernels add the chunks in a fixed
 //    order: the result does not depend on which wave ran which chunk (bitwise reproducible);
 //  * the traversal stack holds only the near-side answers of the levels whose far side is being
-//    searched (push on the way into the far side, pop on the way back): 4 entries per lane in
+//    searched (push on the way into the far side, pop on the way back): 2 entries per lane in
 //    LDS instead of one per tree level; deeper nestings spill to a per-lane column in HBM
 //    (counted in sum [11]);
 //  * leaf buckets are scanned by (queries x bucket parts) tiles: the g lanes of a wave that wait
@@ -79,7 +79,7 @@ namespace icp_dev
             float4 qb[kWave]; // queries by rank in the group, then their results
             double sums[kCovSums + 4]; // this wave's running totals (fixed summation order)
         };
-        static_assert(sizeof(WaveLds) <= 8192, "LDS budget: 4 waves x 8 KiB = 32 KiB per workgroup");
+        static_assert(sizeof(WaveLds) <= 5296, "LDS budget: 7 workgroups of 4 waves on a CU (7 x 4 x 5296 B = 148 KB)");
         static_assert(offsetof(WaveLds, by) - offsetof(WaveLds, bx) == (kImage + 4) * sizeof(float) &&
                           offsetof(WaveLds, bz) - offsetof(WaveLds, by) == (kImage + 4) * sizeof(float),
                       "tile_scan addresses by and bz relative to bx");
