@@ -668,7 +668,7 @@ namespace
     // re-ordered, 3 ms for the pass itself).  Decided on the host where it reads the loop state
     // anyway -- after iterations 1, 3, 7, 15, 23, .. (the ends of the enqueue blocks), in both
     // loops, from state bits that are the same in both -- and at most once per registration:
-    // when the last iteration applied moved no point by more than 2 % of the point spacing and
+    // when the last iteration applied moved no point by more than 5 % of the point spacing and
     // at least four more iterations may follow.  Which order the shard is stored in never
     // changes an answer; it changes the order of the fp64 sums, like any other change of the
     // shard's order.  With an RCCL communicator every rank reads the same state after the
@@ -676,13 +676,27 @@ namespace
     // rank); there the last iteration applied is one ahead of the last one finished, which is
     // why the test is on `started`.
     constexpr uint64_t kResortMinPoints = 1u << 19;
-    bool at_block_end(uint32_t it)
+    // While the pass is still to come on a very large shard (an iteration takes milliseconds, a
+    // read-back 25 us) the enqueue blocks stay at 2 iterations, so that the decision is taken
+    // within two iterations of the clouds being aligned: block ends 1, 3, 5, 7, ..
+    constexpr uint64_t kResortFineBlocksFrom = 8u << 20;
+    bool resort_fine_blocks(const icp_hip_ctx* c)
+    {
+        const char* env = std::getenv("ICP_HIP_RESORT");
+        return !c->resorted && c->sorted && c->leaf_ordered && !c->allreduce &&
+               c->n_local >= kResortFineBlocksFrom && !(env && env[0] == '0');
+    }
+    uint32_t next_block(const icp_hip_ctx* c, uint32_t block)
+    {
+        return std::min(block * 2, resort_fine_blocks(c) ? 2u : (uint32_t)kLoopBlockMax);
+    }
+    bool at_block_end(const icp_hip_ctx* c, uint32_t it) // only asked while the pass is to come
     {
         uint32_t end = 0, block = 1;
         while (end < it)
         {
             end += block;
-            block = std::min(block * 2, (uint32_t)kLoopBlockMax);
+            block = next_block(c, block);
         }
         return end == it;
     }
@@ -690,7 +704,7 @@ namespace
     {
         if (c->resorted || !c->sorted || !c->leaf_ordered || c->allreduce ||
             c->n_local < kResortMinPoints || st.done || st.started == 0 ||
-            st.max_iters - st.started < 4u || !at_block_end(st.started) || !(c->q_extent > 0.0))
+            st.max_iters - st.started < 4u || !at_block_end(c, st.started) || !(c->q_extent > 0.0))
             return ICP_HIP_OK;
         {
             const char* env = std::getenv("ICP_HIP_RESORT");
@@ -714,7 +728,11 @@ namespace
         const double radius = 0.5 * std::sqrt(3.0) * c->q_extent;
         const double moved = std::sqrt(fro) * radius + std::sqrt(v2);
         const double spacing = c->q_extent / std::cbrt((double)c->n_tree_points);
-        if (!(moved < 0.02 * spacing))
+        if (const char* env = std::getenv("ICP_HIP_RESORT"))
+            if (env[0] == 'v') // verbose: what the decision was taken from
+                std::fprintf(stderr, "[resort] after iteration %u: moved <= %.3g, point spacing %.3g\n",
+                             st.started, moved, spacing);
+        if (!(moved < 0.05 * spacing))
             return ICP_HIP_OK;
         c->resorted = true;
         return leaf_order_pass(c, (uint32_t)c->n_local, st.mu_q);
@@ -1085,9 +1103,9 @@ namespace
             }
             it_done = st.it;
             done = st.done != 0;
-            block = std::min(block * 2, (uint32_t)kLoopBlockMax);
             if (!done && (rc = maybe_resort(c, st)) != ICP_HIP_OK)
                 return rc;
+            block = next_block(c, block);
         }
         if (slots == 0) // no iteration at all: read the initial state back
         {
