@@ -99,6 +99,19 @@ namespace icp_dev
             m = fminf(m, v);
         }
 
+        // Running minima of the descent chain on the bit patterns (one integer min each instead
+        // of a canonicalising move + float min).  d2 is >= 0, where floats order like unsigned
+        // integers.  lb may be slightly negative (the bound minus its slack): as a signed integer
+        // any negative float is below every non-negative one, so the chain's bound turns negative
+        // and stays so, which is all that matters (no distance is below it: the lane climbs the
+        // long way); a NaN (a +inf centre distance against a +inf radius) reads as a large
+        // positive integer and never lowers the bound, as with fminf.
+        __device__ __forceinline__ void chain_min(float& chain_lb, float& chain_d2, float lb, float d2)
+        {
+            chain_lb = __int_as_float(min(__float_as_int(chain_lb), __float_as_int(lb)));
+            chain_d2 = __uint_as_float(min(__float_as_uint(chain_d2), __float_as_uint(d2)));
+        }
+
         // ---- fixed-order wave sums of doubles without LDS traffic (gfx950 permlane swaps) ----
         // [a | b] : lanes 0..31 get a[l] + a[l+32], lanes 32..63 get b[l-32] + b[l]
         __device__ __forceinline__ double swap_add_halves(double a, double b)
@@ -535,8 +548,7 @@ namespace icp_dev
                             const float lb = __fsub_rn(
                                 fabsf(__fsub_rn(N.r, da)),
                                 __fadd_rn(__fmul_rn(__fadd_rn(da, N.r), 0x1p-20f), 1e-18f));
-                            chain_lb = fminf(chain_lb, lb);
-                            chain_d2 = fminf(chain_d2, d2);
+                            chain_min(chain_lb, chain_d2, lb, d2);
                             const int go = d2 < N.thr ? N.inside : N.outside; // :147-148
                             if (go >= 0)
                                 node = go;
@@ -593,8 +605,7 @@ namespace icp_dev
                                 const float lb = __fsub_rn(
                                     fabsf(__fsub_rn(N.r, da)),
                                     __fadd_rn(__fmul_rn(__fadd_rn(da, N.r), 0x1p-20f), 1e-18f));
-                                chain_lb = fminf(chain_lb, lb);
-                                chain_d2 = fminf(chain_d2, d2);
+                                chain_min(chain_lb, chain_d2, lb, d2);
                             }
                             const int nearc = in_near ? N.inside : N.outside;
                             const int farc = in_near ? N.outside : N.inside;
