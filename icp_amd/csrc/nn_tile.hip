@@ -224,16 +224,21 @@ namespace icp_dev
                 // is staged (+inf behind the bucket), group kGroups is the +inf pad; only a scan
                 // that can step past it (P * steps > kGroups + 1: long buckets in many parts)
                 // clamps its offsets.
-                const char* const img = reinterpret_cast<const char*>(L.bx);
-                const char* gp = img + (idle ? 0u : 16u * part); // this lane's group in bx
+                // (LDS pointers, 32 bits wide: the select that keeps the best group is one
+                // instruction, where a generic pointer takes a second one for its high half)
+                typedef const __attribute__((address_space(3))) char* lds_ptr;
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                typedef const __attribute__((address_space(3))) v4f* lds_f4;
+                lds_ptr const img = (lds_ptr)L.bx;
+                lds_ptr gp = img + (idle ? 0u : 16u * part); // this lane's group in bx
                 const uint32_t gstride = 16u * P;
                 const float m_before = m;
-                const char* bp = img; // group of the smallest minimum so far
+                lds_ptr bp = img; // group of the smallest minimum so far
                 constexpr uint32_t kBy = (kImage + 4) * sizeof(float), kBz = 2u * kBy;
-                auto step = [&](const char* at) {
-                    const float4 X = *reinterpret_cast<const float4*>(at);
-                    const float4 Y = *reinterpret_cast<const float4*>(at + kBy);
-                    const float4 Z = *reinterpret_cast<const float4*>(at + kBz);
+                auto step = [&](lds_ptr at) {
+                    const v4f X = *(lds_f4)(at);
+                    const v4f Y = *(lds_f4)(at + kBy);
+                    const v4f Z = *(lds_f4)(at + kBz);
                     const float d0 = sq_dist_fma(q.x, q.y, q.z, X.x, Y.x, Z.x);
                     const float d1 = sq_dist_fma(q.x, q.y, q.z, X.y, Y.y, Z.y);
                     const float d2 = sq_dist_fma(q.x, q.y, q.z, X.z, Y.z, Z.z);
@@ -255,7 +260,7 @@ namespace icp_dev
                 }
                 else
                 {
-                    const char* const pad = img + 16u * (uint32_t)kGroups;
+                    lds_ptr const pad = img + 16u * (uint32_t)kGroups;
 #pragma nounroll
                     for (uint32_t k = 0; k < steps; ++k)
                     {
@@ -266,9 +271,9 @@ namespace icp_dev
                 if (m < m_before)
                 {
                     // the winning group again: slot of m and the runner-up inside the group
-                    const float4 X = *reinterpret_cast<const float4*>(bp);
-                    const float4 Y = *reinterpret_cast<const float4*>(bp + kBy);
-                    const float4 Z = *reinterpret_cast<const float4*>(bp + kBz);
+                    const v4f X = *(lds_f4)(bp);
+                    const v4f Y = *(lds_f4)(bp + kBy);
+                    const v4f Z = *(lds_f4)(bp + kBz);
                     const float d0 = sq_dist(q.x, q.y, q.z, X.x, Y.x, Z.x);
                     const float d1 = sq_dist(q.x, q.y, q.z, X.y, Y.y, Z.y);
                     const float d2 = sq_dist(q.x, q.y, q.z, X.z, Y.z, Z.z);
