@@ -3,7 +3,7 @@
 The parity tests (test_gpu_nn_parity.py) already run on this kernel; here the paths that ordinary
 inputs touch rarely are forced and checked against the oracle / the level-stack kernel:
 
-* the overflow of the 4-entry LDS traversal stack into HBM (deeply nested far-side searches);
+* the overflow of the 2-entry LDS traversal stack into HBM (deeply nested far-side searches);
 * buckets larger than one staged window (> 256 slots) and buckets of a single point;
 * every ordering of the shard (as given, Morton, Morton + leaf order) gives the same answers in
   the caller's order;
@@ -47,7 +47,7 @@ def _same(a, b):
 
 
 def test_stack_spill_matches_oracle(oracle):
-    """Small buckets + a grossly misaligned cloud: far sides nest deeper than the 7 LDS entries."""
+    """Small buckets + a grossly misaligned cloud: far sides nest deeper than the LDS entries."""
     from icp_amd import capi, synth
     n, cap = 60_000, 4
     m = synth.cloud(n, seed=5)
@@ -109,8 +109,14 @@ def test_orderings_agree(oracle):
     base = _nn(capi, tree, p, mu_p)
     for env in ({"ICP_HIP_SORT_QUERIES": "0"}, {"ICP_HIP_LEAF_ORDER": "0"},
                 {"ICP_HIP_TILE_CUT": "0"}, {"ICP_HIP_TILE_CUT": "4"},
-                {"ICP_HIP_NN_KERNEL": "deep"}):
-        _same(_nn(capi, tree, p, mu_p, env), base)
+                {"ICP_HIP_NN_KERNEL": "deep"},
+                # how the work is cut and how many workgroups share a CU never shows either
+                {"ICP_HIP_CHUNK_BATCHES": "1"}, {"ICP_HIP_CHUNK_BATCHES": "8"},
+                {"ICP_HIP_TILE_WGS_PER_CU": "1"}, {"ICP_HIP_TILE_WGS_PER_CU": "5"}):
+        got = _nn(capi, tree, p, mu_p, env)
+        _same(got, base)
+        assert got["timing"]["nodes_visited"] == base["timing"]["nodes_visited"]
+        assert got["timing"]["points_scanned"] == base["timing"]["points_scanned"]
     tree.close()
 
 
