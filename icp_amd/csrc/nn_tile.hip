@@ -531,6 +531,9 @@ namespace icp_dev
                 // (vp-tree.cc:147-150 only); the general loop below does the same steps among
                 // its other cases, at three times the instructions ----
                 const unsigned long long cy_d0 = now();
+                // waves that step through nodes wait on memory most of the time: when one of them
+                // is ready it goes first, the scanning waves fill the issue slots in between
+                __builtin_amdgcn_s_setprio(1);
                 if (t.root >= 0)
                 {
                     for (;;)
@@ -577,6 +580,7 @@ namespace icp_dev
                 {
                     // ---- node phase: step every lane until it waits on a bucket or is done ----
                     const unsigned long long cy_n0 = now();
+                    __builtin_amdgcn_s_setprio(1);
                     for (;;)
                     {
                         const uint64_t stepping = __ballot(mode <= tReturn);
@@ -708,6 +712,7 @@ namespace icp_dev
                     }
                     const unsigned long long cy_n1 = now();
                     cy_node += cy_n1 - cy_n0;
+                    __builtin_amdgcn_s_setprio(0);
                     // ---- leaf phase: serve the waiting lanes bucket by bucket ----
                     uint64_t pend = __ballot(mode == tWaitLeaf);
                     if (pend == 0ull)
