@@ -118,3 +118,30 @@ def test_finite_cloud_with_an_fp32_overflowing_extent_is_accepted(n):
         out = ctx.nn(np.zeros(3, np.float32), want=("row",))
     assert out["row"].shape == (n,) and (out["row"] < len(m)).all()
     tree.close()
+
+
+@pytest.mark.parametrize("n", [3000, 20000, 700000])
+def test_call_orders_other_than_tree_then_queries(n):
+    """The shard uploaded before there is a tree (no leaf order, no second ordering pass), the
+    tree replaced under a shard that stays, a second run that continues from the moved cloud:
+    the registration is the one of the usual order (small, unsorted, sorted and re-sorted sizes)."""
+    import icp_amd
+    from icp_amd import capi, synth
+    m = synth.cloud(n, seed=1)
+    p = synth.apply_fp32(m, synth.ground_truth(1.0))
+    mu_m = capi.mean_host(m)
+    mc = capi.center_host(m, mu_m)
+    T0, p0, info = icp_amd.icp(m, p, 30, 1e-5, 64, return_info=True)
+    with capi.Context() as ctx:
+        ctx.set_queries(p)
+        ctx.build_tree(mc, 64)
+        T, it, err = ctx.run(mu_m, 30, 1e-5)
+        assert it == info["iterations"] and np.abs(T - T0).max() <= 1e-6
+        assert np.abs(ctx.get_points() - p0).max() <= 1e-6
+        ctx.build_tree(mc, 16)
+        ctx.set_queries(p)
+        T, it, err = ctx.run(mu_m, 30, 1e-5)
+        assert it == info["iterations"] and np.abs(T - T0).max() <= 1e-6
+        T, it, err = ctx.run(mu_m, 5, 0.0)
+        assert it == 5 and np.abs(T - np.eye(4, dtype=np.float32)).max() <= 1e-5
+        assert np.abs(ctx.get_points() - m).max() < 1e-4
