@@ -216,7 +216,10 @@ namespace icp_dev
                     if (s != kDone)
                     {
                         const Seg S = segs[s];
-                        if (i != S.hi - 1)
+                        // (i inside its segment's range: always, unless this is a speculative
+                        // build whose assumed split of a level above turned out wrong -- its
+                        // result is thrown away, but nothing may be written out of bounds)
+                        if (i != S.hi - 1 && i >= S.lo && i < S.hi)
                         {
                             const uint32_t ni = so[s].ni;
                             const uint32_t rank_in = scan[i] - scan[S.lo];
@@ -234,6 +237,11 @@ namespace icp_dev
                             else
                                 key_out = key;
                         }
+                    }
+                    if (pos >= n) // (same: a mis-assumed layout; never on a build that is kept)
+                    {
+                        pos = i;
+                        pr = kDone;
                     }
                     ox[pos] = x[i];
                     oy[pos] = y[i];
@@ -287,6 +295,8 @@ namespace icp_dev
                 return; // empty side: the host reports the degenerate cloud
             const uint32_t k = 0xFFFFFFFFu - (uint32_t)best[c];
             const uint32_t a = lo + k, b = hi - 1;
+            if (k >= hi - lo)
+                return; // no candidate recorded (possible only under a mis-assumed layout)
             if (a != b)
             {
                 float t;
@@ -372,8 +382,40 @@ namespace icp_dev
         }                                                                                        \
     } while (0)
 
+    namespace
+    {
+        // `speculate`: the whole build is enqueued without a single read-back.  What the host needs
+        // from a level to lay out the next one is only how many points fell inside each median
+        // sphere, and with distinct distances that is floor(m / 2) by construction
+        // (vp-tree.cc:48-52,:92); the host assumes it, the levels' records stay on the device and
+        // are checked in one read-back at the end.  A level costs ~0.15 ms of synchronisation and
+        // launch gaps whatever its size, which is most of the build below a million points (the
+        // 48k-point horse, 8 levels: 1.12 -> 0.6 ms).  A tie at a median (or a degenerate split)
+        // sets *mispredicted and the caller builds again level by level.
+        int build_tree_device_impl(const float* d_aos, uint32_t n, uint32_t capacity, hipStream_t st,
+                                   BuiltTree& out, std::string& err, bool speculate,
+                                   bool* mispredicted);
+    } // namespace
+
     int build_tree_device(const float* d_aos, uint32_t n, uint32_t capacity, hipStream_t st,
                           BuiltTree& out, std::string& err)
+    {
+        constexpr uint32_t kSpeculateBelow = 4u << 20;
+        if (n < kSpeculateBelow)
+        {
+            bool mispredicted = false;
+            const int rc = build_tree_device_impl(d_aos, n, capacity, st, out, err, true, &mispredicted);
+            if (!mispredicted)
+                return rc;
+            err.clear();
+        }
+        return build_tree_device_impl(d_aos, n, capacity, st, out, err, false, nullptr);
+    }
+
+    namespace
+    {
+    int build_tree_device_impl(const float* d_aos, uint32_t n, uint32_t capacity, hipStream_t st,
+                               BuiltTree& out, std::string& err, bool speculate, bool* mispredicted)
     {
         out = BuiltTree{};
         // ---- working set ----
@@ -400,6 +442,9 @@ namespace icp_dev
         const size_t max_seg = (size_t)n / (capacity ? capacity : 1) + 2;
         TB_TRY(segs.alloc(max_seg));
         TB_TRY(segout.alloc(max_seg));
+        Buf<SegOut> segout_all; // speculate: every level's records, node id = index
+        if (speculate)
+            TB_TRY(segout_all.alloc((size_t)n + 1));
         TB_TRY(best.alloc(2 * max_seg));
         TB_TRY(remap.alloc(2 * max_seg));
         size_t tmp_sort = 0, tmp_scan = 0;
@@ -416,6 +461,12 @@ namespace icp_dev
         hipLaunchKernelGGL(init_kernel, dim3(grid_n(n)), dim3(kB), 0, st, d_aos, n, x[0].p, y[0].p,
                            z[0].p, row[0].p, prov.p, non_finite.p);
         TB_TRY(hipGetLastError());
+        auto mispredict = [&]() {
+            (void)hipStreamSynchronize(st);
+            *mispredicted = true;
+            return 0;
+        };
+        if (!speculate) // (the speculative build reads the flag back with everything else)
         {
             uint32_t h_bad = 0;
             TB_TRY(hipMemcpyAsync(&h_bad, non_finite.p, sizeof h_bad, hipMemcpyDeviceToHost, st));
@@ -443,6 +494,7 @@ namespace icp_dev
             int side;
         };
         std::vector<HNode> nodes;
+        std::vector<uint32_t> spec_ni; // speculate: the inside count assumed for each node
         std::vector<HLeaf> leaves;
         struct Cur
         {
@@ -478,6 +530,8 @@ namespace icp_dev
                 off += level[s].hi - level[s].lo;
                 if (level[s].hi - level[s].lo < 2)
                 {
+                    if (speculate)
+                        return mispredict();
                     err = "degenerate cloud: a one-point internal node (median of an empty array in "
                           "the reference, vp-tree.cc:77)";
                     return 2;
@@ -497,32 +551,45 @@ namespace icp_dev
             size_t tb = tmp_bytes;
             TB_TRY(rocprim::radix_sort_keys(tmp.p, tb, keys.p, sorted.p, (size_t)n, 0u,
                                             32u + seg_bits, st));
+            // (speculate: this level's records at its nodes' ids, which are handed out in this order)
+            SegOut* const so_dev = speculate ? segout_all.p + nodes.size() : segout.p;
             hipLaunchKernelGGL(median_kernel, dim3((S + kB - 1) / kB), dim3(kB), 0, st, segs.p, S,
-                               sorted.p, x[cur].p, y[cur].p, z[cur].p, row[cur].p, segout.p);
-            hipLaunchKernelGGL(flag_kernel, dim3(grid_n(n)), dim3(kB), 0, st, seg.p, segs.p, segout.p,
+                               sorted.p, x[cur].p, y[cur].p, z[cur].p, row[cur].p, so_dev);
+            hipLaunchKernelGGL(flag_kernel, dim3(grid_n(n)), dim3(kB), 0, st, seg.p, segs.p, so_dev,
                                d2.p, n, flag.p);
             TB_TRY(hipGetLastError());
             tb = tmp_bytes;
             TB_TRY(rocprim::exclusive_scan(tmp.p, tb, flag.p, scan.p, 0u, (size_t)n,
                                            rocprim::plus<uint32_t>(), st));
             hipLaunchKernelGGL(count_kernel, dim3((S + kB - 1) / kB), dim3(kB), 0, st, segs.p, S,
-                               scan.p, segout.p);
+                               scan.p, so_dev);
             // contiguous runs of a multiple of 64 points per wave, every wave of the grid busy
             const uint32_t sc_grid = grid_n(n);
             const uint64_t sc_waves = (uint64_t)sc_grid * (kB / 64);
             const uint32_t per_wave = (uint32_t)(((uint64_t)n + sc_waves * 64 - 1) / (sc_waves * 64)) * 64u;
             hipLaunchKernelGGL(scatter_kernel, dim3(sc_grid), dim3(kB), 0, st, seg.p, segs.p,
-                               segout.p, scan.p, flag.p, d2.p, x[cur].p, y[cur].p, z[cur].p,
+                               so_dev, scan.p, flag.p, d2.p, x[cur].p, y[cur].p, z[cur].p,
                                row[cur].p, n, per_wave, x[cur ^ 1].p, y[cur ^ 1].p, z[cur ^ 1].p,
                                row[cur ^ 1].p, prov.p, best.p);
             hipLaunchKernelGGL(swap_kernel, dim3((2 * S + kB - 1) / kB), dim3(kB), 0, st, segs.p,
-                               segout.p, S, best.p, x[cur ^ 1].p, y[cur ^ 1].p, z[cur ^ 1].p,
+                               so_dev, S, best.p, x[cur ^ 1].p, y[cur ^ 1].p, z[cur ^ 1].p,
                                row[cur ^ 1].p);
             TB_TRY(hipGetLastError());
             h_out.resize(S);
-            TB_TRY(hipMemcpyAsync(h_out.data(), segout.p, S * sizeof(SegOut), hipMemcpyDeviceToHost,
-                                  st));
-            TB_TRY(hipStreamSynchronize(st));
+            if (speculate)
+            {
+                for (uint32_t s = 0; s < S; ++s)
+                {
+                    h_out[s] = SegOut{};
+                    h_out[s].ni = (level[s].hi - level[s].lo - 1) / 2; // the rank of the median
+                }
+            }
+            else
+            {
+                TB_TRY(hipMemcpyAsync(h_out.data(), segout.p, S * sizeof(SegOut),
+                                      hipMemcpyDeviceToHost, st));
+                TB_TRY(hipStreamSynchronize(st));
+            }
             cur ^= 1;
 
             // ---- this level's node records (breadth-first ids) and the next level ----
@@ -534,6 +601,8 @@ namespace icp_dev
                 const SegOut& o = h_out[s];
                 const uint32_t lo = level[s].lo, hi = level[s].hi, m = hi - lo - 1;
                 const uint32_t ni = o.ni, no = m - ni;
+                if ((ni == 0 || no == 0) && speculate)
+                    return mispredict();
                 if (ni == 0 || no == 0)
                 {
                     err = "degenerate cloud: a vantage-point split left one side empty (duplicate "
@@ -543,6 +612,8 @@ namespace icp_dev
                 }
                 HNode nd{o.cx, o.cy, o.cz, std::sqrt(o.r2), 0, 0, level[s].parent, o.crow};
                 nodes.push_back(nd);
+                if (speculate)
+                    spec_ni.push_back(ni);
             }
             for (uint32_t s = 0; s < S; ++s)
             {
@@ -568,6 +639,31 @@ namespace icp_dev
             }
             height = ++depth;
             level.swap(next);
+        }
+
+        if (speculate)
+        {
+            // one read-back: the non-finite flag and every node's record; a count that is not
+            // the assumed one (equal distances at a median) voids the layout of the levels below
+            uint32_t h_bad = 0;
+            std::vector<SegOut> all(nodes.size());
+            TB_TRY(hipMemcpyAsync(&h_bad, non_finite.p, sizeof h_bad, hipMemcpyDeviceToHost, st));
+            if (!all.empty())
+                TB_TRY(hipMemcpyAsync(all.data(), segout_all.p, all.size() * sizeof(SegOut),
+                                      hipMemcpyDeviceToHost, st));
+            TB_TRY(hipStreamSynchronize(st));
+            if (h_bad)
+                return mispredict(); // (the level-by-level build words the error)
+            for (size_t id = 0; id < all.size(); ++id)
+            {
+                if (all[id].ni != spec_ni[id])
+                    return mispredict();
+                nodes[id].cx = all[id].cx;
+                nodes[id].cy = all[id].cy;
+                nodes[id].cz = all[id].cz;
+                nodes[id].r = std::sqrt(all[id].r2);
+                nodes[id].row = all[id].crow;
+            }
         }
 
         // ---- leaves left to right == ascending position; buckets padded to 16 slots ----
@@ -646,4 +742,5 @@ namespace icp_dev
         out.d_srow = srow.take();
         return 0;
     }
+    } // namespace
 } // namespace icp_dev
