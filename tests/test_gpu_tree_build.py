@@ -138,3 +138,33 @@ def test_small_clouds_take_the_host_builder_and_give_the_same_tree(clouds, monke
     same_tree(trees[0], trees[2])
     for t in trees:
         t.close()
+
+
+@pytest.mark.parametrize("cap", [4, 16, 64])
+def test_ties_at_a_median_take_the_level_by_level_build(cap):
+    """Below 4M points the device build is speculative: the host lays out every level assuming
+    that floor(m / 2) points fall strictly inside each median sphere and checks the counts once
+    at the end (tree_build.hip).  On a lattice many points are equally far from a vantage point,
+    the assumption fails somewhere, and the build must notice and start over level by level: the
+    tree is still the host builder's (the reference's, vp-tree.cc:48-52,:92) array by array --
+    or the same degenerate-cloud error where the reference's build is undefined."""
+    from icp_amd import capi
+    g = np.arange(-12, 13, dtype=np.float32)
+    lattice = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    rng = np.random.default_rng(cap)
+    # a little anisotropy keeps most splits non-degenerate while leaving many exact ties
+    m = (lattice * np.array([1.0, 1.5, 2.0], np.float32))[rng.permutation(len(lattice))]
+    mc = centred(capi, m)
+    try:
+        host = capi.FlatTree(mc, cap)
+    except capi.IcpHipError as e:
+        with capi.Context() as ctx, pytest.raises(capi.IcpHipError) as d:
+            ctx.build_tree(mc, cap)
+        assert d.value.status == e.status == 2
+        return
+    with capi.Context() as ctx:
+        ctx.build_tree(mc, cap)
+        dev = ctx.get_tree()
+    same_tree(dev, host)
+    dev.close()
+    host.close()
