@@ -202,13 +202,33 @@ def main():
 
     # the reference's tree, built in HBM (icp_hip_build_tree; bit-identical to the host build)
     ctx = capi.Context(local_rank)
+    # The per-iteration all-reduce: the context's own RCCL communicator, enqueued on its stream
+    # between the kernels (xGMI).  More than one RCCL rank has never run where this was built
+    # (one GPU per box): if the communicator does not come up on EVERY rank, all ranks fall back
+    # together to the host-callback all-reduce through torch.distributed (the path the 2-rank
+    # tests cover), and the line says so.
+    allreduce_path = "none (one rank)"
+    if world > 1:
+        allreduce_path = "rccl communicator on the context's stream"
+        try:
+            init_rccl(ctx, world, rank)
+            ok = 1.0
+        except Exception as e:  # capi.IcpHipError, or the rendezvous
+            print(f"[bench rank {rank}] RCCL communicator failed: {e}", file=sys.stderr, flush=True)
+            ok = 0.0
+        flag = torch.tensor([ok], dtype=torch.float64, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if flag.item() < 1.0:
+            from icp_amd.dist import torch_allreduce
+            ctx.close()
+            ctx = capi.Context(local_rank)
+            ctx.set_allreduce(torch_allreduce(device=torch.device("cuda", local_rank)))
+            allreduce_path = "FALLBACK: torch.distributed all-reduce from the host loop"
     ctx.build_tree(mc[:4096], args.capacity)   # first-call costs (code load) out of the timing
     t0 = time.time()
     ctx.build_tree(mc, args.capacity)
     t_build = time.time() - t0
     tinfo = ctx.tree_info()
-    if world > 1:
-        init_rccl(ctx, world, rank)  # the context's own RCCL communicator (xGMI)
 
     # achievable streaming bandwidth of this GPU beside the 8 TB/s spec peak: a plain
     # device-to-device copy of 1 GiB through torch (plumbing), bytes read + written per second
@@ -337,7 +357,8 @@ def main():
                                    f"({end - begin} per GPU), rigid motion {args.angle} deg",
                        "reference_points": n_m, "queries_total": n_queries_total,
                        "queries_per_gpu": end - begin, "capacity": args.capacity,
-                       "tree_height": int(tinfo["height"]), "parallelism": f"query-shard x{world}"},
+                       "tree_height": int(tinfo["height"]), "parallelism": f"query-shard x{world}",
+                       "allreduce": allreduce_path},
             "icp_iterations_per_sec": round(args.steps / dt, 3),
             "nn_kernel_queries_per_sec": round((end - begin) * world / avg_s, 1),
             "nn_ms_first_iter": round(float(trace[0]), 4) if len(trace) else None,
