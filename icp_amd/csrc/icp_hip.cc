@@ -270,6 +270,8 @@ struct icp_hip_ctx
     DevBuf<uint32_t> perm; // sorted position -> input row (Morton order), empty when unsorted
     bool sorted = false;
     bool leaf_ordered = false, resorted = false; // see maybe_resort
+    bool resort_decided = false; // with a communicator: the decision every rank takes alike
+    float root_radius = 0.f;     // radius of the tree's root sphere (the same tree on every rank)
     double q_extent = 0.0; // largest side of the shard's bounding box at set-up
     DevBuf<uint32_t> sk_keys, sk_keys2, sk_idx, sk_order; // the sorts' arrays, kept for maybe_resort
     DevBuf<unsigned char> sk_temp;
@@ -680,11 +682,29 @@ namespace
     // read-back 25 us) the enqueue blocks stay at 2 iterations, so that the decision is taken
     // within two iterations of the clouds being aligned: block ends 1, 3, 5, 7, ..
     constexpr uint64_t kResortFineBlocksFrom = 8u << 20;
+    // With an RCCL communicator every rank must enqueue the same number of slots (each holds a
+    // collective) although it reads `done` only at its block ends: the block sizes, and with
+    // them the decision about the pass, may then depend on nothing a single rank sees -- not on
+    // its shard's size, extent or order.  There the decision is taken from the all-reduced loop
+    // state, the tree (the same on every rank) and n_total / n_ranks; whether a rank then runs
+    // the pass on its own shard is its own business.
+    // (One rank sees everything: its communicator run stays bit-identical to the plain run.
+    // ICP_HIP_RESORT=g applies the many-rank rule to a communicator of one rank, for the tests.)
+    bool resort_rule_global(const icp_hip_ctx* c)
+    {
+        const char* env = std::getenv("ICP_HIP_RESORT");
+        return c->comm && (c->n_ranks > 1 || (env && env[0] == 'g'));
+    }
     bool resort_fine_blocks(const icp_hip_ctx* c)
     {
         const char* env = std::getenv("ICP_HIP_RESORT");
+        if (env && env[0] == '0')
+            return false;
+        if (resort_rule_global(c))
+            return !c->resort_decided &&
+                   c->n_total / (uint64_t)(c->n_ranks > 0 ? c->n_ranks : 1) >= kResortFineBlocksFrom;
         return !c->resorted && c->sorted && c->leaf_ordered && !c->allreduce &&
-               c->n_local >= kResortFineBlocksFrom && !(env && env[0] == '0');
+               c->n_local >= kResortFineBlocksFrom;
     }
     uint32_t next_block(const icp_hip_ctx* c, uint32_t block)
     {
@@ -702,15 +722,25 @@ namespace
     }
     int maybe_resort(icp_hip_ctx* c, const LoopState& st)
     {
-        if (c->resorted || !c->sorted || !c->leaf_ordered || c->allreduce ||
-            c->n_local < kResortMinPoints || st.done || st.started == 0 ||
-            st.max_iters - st.started < 4u || !at_block_end(c, st.started) || !(c->q_extent > 0.0))
-            return ICP_HIP_OK;
         {
             const char* env = std::getenv("ICP_HIP_RESORT");
             if (env && env[0] == '0')
                 return ICP_HIP_OK;
         }
+        const bool sharded = resort_rule_global(c);
+        // what this rank's shard allows (never part of a decision that shapes the blocks)
+        const bool can = c->sorted && c->leaf_ordered && c->n_local >= kResortMinPoints &&
+                         c->q_extent > 0.0;
+        if (sharded ? c->resort_decided : (c->resorted || !can))
+            return ICP_HIP_OK;
+        if (c->allreduce || st.done || st.started == 0 || st.max_iters - st.started < 4u ||
+            !at_block_end(c, st.started))
+            return ICP_HIP_OK;
+        // the scale the motion is compared with: the shard's own extent, or with a communicator
+        // the diameter of the tree's root sphere (a median distance: about the cloud's extent)
+        const double extent = sharded ? 2.0 * (double)c->root_radius : c->q_extent;
+        if (!(extent > 0.0))
+            return ICP_HIP_OK;
         // the last iteration moved x to R x + t: by at most |R - I|_F |x - mu_m| + |R mu_m + t - mu_m|
         const float* T = st.Tn;
         double fro = 0.0, v2 = 0.0;
@@ -725,14 +755,17 @@ namespace
             }
             v2 += v * v;
         }
-        const double radius = 0.5 * std::sqrt(3.0) * c->q_extent;
+        const double radius = 0.5 * std::sqrt(3.0) * extent;
         const double moved = std::sqrt(fro) * radius + std::sqrt(v2);
-        const double spacing = c->q_extent / std::cbrt((double)c->n_tree_points);
+        const double spacing = extent / std::cbrt((double)c->n_tree_points);
         if (const char* env = std::getenv("ICP_HIP_RESORT"))
             if (env[0] == 'v') // verbose: what the decision was taken from
                 std::fprintf(stderr, "[resort] after iteration %u: moved <= %.3g, point spacing %.3g\n",
                              st.started, moved, spacing);
         if (!(moved < 0.05 * spacing))
+            return ICP_HIP_OK;
+        c->resort_decided = true;
+        if (!can || c->resorted)
             return ICP_HIP_OK;
         c->resorted = true;
         return leaf_order_pass(c, (uint32_t)c->n_local, st.mu_q);
@@ -755,6 +788,7 @@ namespace
         const size_t nn = t->n_nodes, nl = t->n_leaves, ns = t->n_slots;
         const size_t slack = kSlotSlack; // bucket windows / chunks are loaded whole
         c->n_leaves = (uint32_t)nl;
+        c->root_radius = nn ? t->node_radius[0] : 0.f;
 
         // A small tree is packed on the host into one block and uploaded with ONE copy: the ten
         // copies, the staging arrays and the packing kernel below cost more than a whole
@@ -1746,7 +1780,7 @@ extern "C"
         DeviceGuard g(c->device);
         c->has_queries = false;
         c->upload_pending = c->host_points_valid = c->first_sums_valid = false;
-        c->leaf_ordered = c->resorted = false;
+        c->leaf_ordered = c->resorted = c->resort_decided = false;
         const size_t n = n_local ? n_local : 1;
         HIP_TRY(c, c->yx.alloc(n));
         HIP_TRY(c, c->yy.alloc(n));

@@ -98,3 +98,25 @@ def test_resort_under_a_communicator_equals_the_plain_run(monkeypatch, world):
     assert res[0][1] == res[1][1] == 16 and res[0][3] == res[1][3]
     assert (bits(res[0][0]) == bits(res[1][0])).all()
     assert (bits(res[0][4]) == bits(res[1][4])).all()
+
+
+def test_many_rank_rule_decides_from_nothing_a_single_rank_sees(monkeypatch, world):
+    """With more than one rank every rank must enqueue the same slots, so the decision about the
+    pass (and the enqueue blocks that depend on it) is taken from the all-reduced loop state and
+    the tree alone, not from the shard (icp_hip.cc, resort_rule_global).  ICP_HIP_RESORT=g applies
+    that rule to a communicator of one rank: the pass still happens, later passes are faster than
+    without it, and the registration is the plain one up to the order of the fp64 sums."""
+    from icp_amd import capi
+    res = {}
+    for mode in ("0", "g"):
+        monkeypatch.setenv("ICP_HIP_RESORT", mode)
+        with capi.Context() as ctx:
+            ctx.build_tree(world["mc"], 256)
+            ctx.comm_init_rank(1, 0, capi.Context.comm_unique_id())
+            ctx.set_queries(world["p"])
+            T, it, err = ctx.run(world["mu_m"], 16, 0.0)
+            res[mode] = (T.copy(), it, ctx.get_points(), ctx.nn_trace())
+    assert res["0"][1] == res["g"][1] == 16
+    assert np.abs(res["0"][0] - res["g"][0]).max() <= 2e-7
+    assert np.abs(res["0"][2] - res["g"][2]).max() <= 1e-6
+    assert np.median(res["g"][3][-4:]) < np.median(res["0"][3][-4:])
