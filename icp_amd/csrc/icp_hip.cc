@@ -460,7 +460,7 @@ namespace
         {
             const char* env = std::getenv("ICP_HIP_TILE_STATS");
             if (env && env[0] == '1')
-                HIP_TRY(c, c->stats.alloc(24));
+                HIP_TRY(c, c->stats.alloc((size_t)kTileStatsWords * kTileStatsCopies));
         }
         HIP_TRY(c, c->chunk_sums.alloc((size_t)c->n_chunks * kCovSums));
         HIP_TRY(c, c->spill.alloc((size_t)c->spill_levels * c->tile_grid_blocks * 256));
@@ -510,7 +510,9 @@ namespace
         TileLaunch q{c->chunk_batches, c->batch_queries, c->chunk_sums.p, c->queue.p,
                      c->spill.p, loop ? nullptr : c->stats.p, c->tile_cut};
         if (q.stats)
-            HIP_TRY(c, hipMemsetAsync(q.stats, 0, 24 * sizeof(unsigned long long), c->stream));
+            HIP_TRY(c, hipMemsetAsync(q.stats, 0,
+                                      sizeof(unsigned long long) * kTileStatsWords * kTileStatsCopies,
+                                      c->stream));
         if (e0)
             HIP_TRY(c, hipEventRecord(e0, c->stream));
         HIP_TRY(c, launch_nn_tile(a, q, c->stream));
@@ -518,9 +520,18 @@ namespace
             HIP_TRY(c, hipEventRecord(e1, c->stream));
         if (q.stats)
         {
-            unsigned long long h[24];
-            HIP_TRY(c, hipMemcpyAsync(h, q.stats, sizeof h, hipMemcpyDeviceToHost, c->stream));
+            std::vector<unsigned long long> copies((size_t)kTileStatsWords * kTileStatsCopies);
+            HIP_TRY(c, hipMemcpyAsync(copies.data(), q.stats, copies.size() * sizeof(unsigned long long),
+                                      hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
+            unsigned long long h[kTileStatsWords] = {};
+            for (int k = 0; k < kTileStatsCopies; ++k)
+                for (int w = 0; w < kTileStatsWords; ++w)
+                {
+                    const unsigned long long v = copies[(size_t)k * kTileStatsWords + w];
+                    const bool is_max = (w >= 15 && w <= 18) || w == 22 || w == 23;
+                    h[w] = is_max ? std::max(h[w], v) : h[w] + v;
+                }
             std::fprintf(stderr,
                          "[tile stats] batches %llu node_iters %llu node_lane_steps %llu "
                          "leaf_phases %llu tile_scans %llu tile_lanes %llu coop_scans %llu "
@@ -530,6 +541,24 @@ namespace
                          h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11],
                          h[12], h[13], h[14], h[21],
                          h[20] ? 100.0 * (double)h[8] / (double)h[20] : 0.0, h[22], h[23]);
+            // when the waves ended, how long they lived and what a batch cost: a pass ends with
+            // its slowest batch, and the waves that found the queues empty idle meanwhile
+            std::fprintf(stderr,
+                         "[tile stats] waves started over %.1f us, ended over %.1f us; first start to "
+                         "last end %.1f us\n",
+                         0.01 * (double)(h[16] - ~h[15]), 0.01 * (double)(h[18] - ~h[17]),
+                         0.01 * (double)(h[18] - ~h[15]));
+            auto histogram = [&](const char* what, int at, unsigned shift) {
+                std::fprintf(stderr, "[tile stats] %s (bins of %u cycles):", what, 1u << shift);
+                int last = 63;
+                while (last > 0 && h[at + last] == 0)
+                    --last;
+                for (int b = 0; b <= last; ++b)
+                    std::fprintf(stderr, " %llu", h[at + b]);
+                std::fprintf(stderr, "\n");
+            };
+            histogram("wave lifetimes", 24, 17);
+            histogram("batch durations", 88, 13);
         }
         // chunk sums (-> <= 1024 partial rows) -> the twelve sums, in a fixed order
         HIP_TRY(c, launch_chunk_sums(c->chunk_sums.p, c->n_chunks, c->partials.p, c->sums.p,

@@ -100,6 +100,12 @@ namespace icp_dev
     // nn_tile.hip: the production kernel (a.partials is not used: sums go to q.chunk_sums)
     constexpr uint32_t kQueueWords = 288; // 8 queue heads, one per 128-byte line, + the count of
                                           // finished workgroups (word 256)
+    // The diagnostic build (ICP_HIP_TILE_STATS=1) counts into kTileStatsCopies copies of its
+    // kTileStatsWords counters (workgroup b adds to copy b % 64; the host adds the copies up):
+    // thousands of waves flushing ~40 counters each to ONE set of words at the end of a pass held
+    // up the memory accesses of the waves still working by ~0.9 ms.
+    constexpr int kTileStatsWords = 24 + 64 + 64;
+    constexpr int kTileStatsCopies = 64;
     struct TileLaunch
     {
         uint32_t chunk_batches; // batches per chunk (1..8)
@@ -111,7 +117,8 @@ namespace icp_dev
         uint32_t* queue;        // kQueueWords words, zero at launch; the last workgroup to finish
                                 // leaves them zero for the next launch
         uint2* spill;           // [max(0, height - stack entries)][grid * 256] or null
-        unsigned long long* stats; // 24 counters of the diagnostic build (events, cycles by phase), or null
+        unsigned long long* stats; // kTileStatsWords x kTileStatsCopies counters of the diagnostic build
+                                   // (events, cycles by phase, histograms), or null
         uint32_t cut; // leave the node phase when waiting lanes >= cut/16 x stepping lanes (0: never)
     };
     hipError_t launch_nn_tile(const NnLaunch& a, const TileLaunch& q, hipStream_t s);

@@ -414,6 +414,8 @@ namespace icp_dev
             unsigned long long cy_node = 0, cy_tile = 0, cy_coop = 0, cy_exact = 0, cy_tail = 0,
                                cy_head = 0, cy_total = 0, cy_pop = 0;
             const unsigned long long rt_begin = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
+            if (STATS)
+                stats += (size_t)(blockIdx.x % (uint32_t)kTileStatsCopies) * kTileStatsWords;
             auto now = [&]() -> unsigned long long {
                 return STATS ? (unsigned long long)__builtin_amdgcn_s_memtime() : 0ull;
             };
@@ -912,10 +914,15 @@ namespace icp_dev
                     }
                 }
                 cy_tail += now() - cy_e0;
+                if (STATS && lane == 0) // histogram of batch durations, bins of 8192 cycles
+                    atomicAdd(stats + 88 + min(63ull, (now() - cy_b0) >> 13), 1ull);
             }
                 if (chunk_sums && lane_c < (uint32_t)kCovSums)
                     chunk_sums[(size_t)chunk * kCovSums + lane_c] = L.sums[lane_c];
             }
+            // (diagnostic build: this wave's end, before the counters below queue up on their words)
+            const unsigned long long rt_end = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
+            cy_total = now() - cy_begin;
             // the last workgroup to get here leaves the queue heads zero for the next launch
             __syncthreads();
             if (threadIdx.x == 0)
@@ -940,7 +947,6 @@ namespace icp_dev
                 atomicAdd(stats + 5, (unsigned long long)st_tile_g);
                 atomicAdd(stats + 6, (unsigned long long)st_coop);
                 atomicAdd(stats + 7, (unsigned long long)st_exact);
-                cy_total = now() - cy_begin;
                 atomicAdd(stats + 8, cy_total);
                 atomicAdd(stats + 9, cy_head);
                 atomicAdd(stats + 10, cy_node);
@@ -948,10 +954,17 @@ namespace icp_dev
                 atomicAdd(stats + 12, cy_tile);
                 atomicAdd(stats + 13, cy_exact);
                 atomicAdd(stats + 14, cy_tail);
-                atomicAdd(stats + 20, (unsigned long long)__builtin_amdgcn_s_memrealtime() - rt_begin);
+                atomicAdd(stats + 20, rt_end - rt_begin);
                 atomicAdd(stats + 21, cy_pop);
                 atomicMax(stats + 22, cy_total);
                 atomicMax(stats + 23, (unsigned long long)st_batch);
+                // histogram of wave lifetimes (bins of 131072 cycles); first / last wave to start
+                // and to end, on the 100 MHz clock all waves share
+                atomicAdd(stats + 24 + min(63ull, cy_total >> 17), 1ull);
+                atomicMax(stats + 15, ~rt_begin);
+                atomicMax(stats + 16, rt_begin);
+                atomicMax(stats + 17, ~rt_end);
+                atomicMax(stats + 18, rt_end);
                 (void)st_tile_len;
             }
         }
