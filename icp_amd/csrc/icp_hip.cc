@@ -559,6 +559,18 @@ namespace
             };
             histogram("wave lifetimes", 24, 17);
             histogram("batch durations", 88, 13);
+            for (int k = 0; k < 2; ++k)
+            {
+                const unsigned long long* q = h + 152 + 9 * k;
+                const double nb = q[0] ? (double)q[0] : 1.0;
+                std::fprintf(stderr,
+                             "[tile stats] batches %s 90112 cycles: %llu, mean %.0f cycles (node phase "
+                             "%.0f, tile scans %.0f, rest of the leaf phases %.0f); per batch %.1f node "
+                             "steps, %.2f leaf phases, %.2f tile scans, %.2f single-lane scans\n",
+                             k ? "from" : "below", q[0], (double)q[1] / nb, (double)q[2] / nb,
+                             (double)q[3] / nb, (double)q[4] / nb, (double)q[5] / nb,
+                             (double)q[6] / nb, (double)q[7] / nb, (double)q[8] / nb);
+            }
         }
         // chunk sums (-> <= 1024 partial rows) -> the twelve sums, in a fixed order
         HIP_TRY(c, launch_chunk_sums(c->chunk_sums.p, c->n_chunks, c->partials.p, c->sums.p,

@@ -104,7 +104,7 @@ namespace icp_dev
     // kTileStatsWords counters (workgroup b adds to copy b % 64; the host adds the copies up):
     // thousands of waves flushing ~40 counters each to ONE set of words at the end of a pass held
     // up the memory accesses of the waves still working by ~0.9 ms.
-    constexpr int kTileStatsWords = 24 + 64 + 64;
+    constexpr int kTileStatsWords = 24 + 64 + 64 + 18;
     constexpr int kTileStatsCopies = 64;
     struct TileLaunch
     {

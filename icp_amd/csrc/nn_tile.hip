@@ -99,18 +99,28 @@ namespace icp_dev
             m = fminf(m, v);
         }
 
-        // Running minima of the descent chain on the bit patterns (one integer min each instead
-        // of a canonicalising move + float min).  d2 is >= 0, where floats order like unsigned
-        // integers.  lb may be slightly negative (the bound minus its slack): as a signed integer
-        // any negative float is below every non-negative one, so the chain's bound turns negative
-        // and stays so, which is all that matters (no distance is below it: the lane climbs the
-        // long way); a NaN (a +inf centre distance against a +inf radius) reads as a large
-        // positive integer and never lowers the bound, as with fminf.
-        __device__ __forceinline__ void chain_min(float& chain_lb, float& chain_d2, float lb, float d2)
+        // One value per level of a descent: m = min(|radius - d|, d) - slack, a lower bound of both
+        // distances that decide whether the level can change an answer on the way back up (an
+        // answer below it passes the prune test, vp-tree.cc:152, and is not beaten by the centre,
+        // :154).  The chain keeps the smallest, the second smallest (with multiplicity) and the
+        // node of the smallest -- on the bit patterns, as signed integers (integer min / max
+        // instead of a canonicalising move + float min each).  m may be slightly negative (the
+        // bound minus its slack): any negative float is below every non-negative one as an
+        // integer too, so the bound turns negative and stays so, which is all that matters (no
+        // distance is below it: the lane climbs the long way); a NaN (a +inf centre distance
+        // against a +inf radius) reads as a large positive integer and never lowers a bound, as
+        // with fminf.
+        __device__ __forceinline__ void chain_track(float& chain_m, float& chain_m2, int& arg, float m,
+                                                    int node)
         {
-            chain_lb = __int_as_float(min(__float_as_int(chain_lb), __float_as_int(lb)));
-            chain_d2 = __uint_as_float(min(__float_as_uint(chain_d2), __float_as_uint(d2)));
+            const int a = __float_as_int(chain_m), b = __float_as_int(chain_m2), v = __float_as_int(m);
+            arg = v < a ? node : arg;
+            chain_m2 = __int_as_float(min(b, max(a, v)));
+            chain_m = __int_as_float(min(a, v));
         }
+        constexpr int kNearMark = (int)0x80000000; // `prev` of a lane that jumped to the one level
+                                                   // of its chain that matters (no child code: there
+                                                   // are fewer than 2^31 leaves)
 
         // ---- fixed-order wave sums of doubles without LDS traffic (gfx950 permlane swaps) ----
         // [a | b] : lanes 0..31 get a[l] + a[l+32], lanes 32..63 get b[l-32] + b[l]
@@ -489,6 +499,10 @@ namespace icp_dev
                 if (STATS)
                     st_batch += 1u;
                 const unsigned long long cy_b0 = now();
+                // (diagnostic build: what this batch adds to the wave's counters)
+                const unsigned long long cy_node_b0 = cy_node, cy_tile_b0 = cy_tile, cy_coop_b0 = cy_coop;
+                const uint32_t st_node_b0 = st_node, st_tile_b0 = st_tile, st_coop_b0 = st_coop,
+                               st_leafph_b0 = st_leafph;
                 const uint32_t i = b * batch_queries + (uint32_t)lane;
                 const bool valid = (uint32_t)lane < batch_queries && i < n;
                 float qx = 0.f, qy = 0.f, qz = 0.f;
@@ -502,13 +516,14 @@ namespace icp_dev
                 int node = t.root, prev = 0;
                 int mode = tDescend;
                 // The current descent chain (from the root, or from the far child of `ret_node`):
-                // `chain_lb` is a lower bound of min |radius - d| over its nodes and `chain_d2` the
-                // smallest squared centre distance.  If the bucket at its end answers with a
-                // distance below chain_lb, every prune test on the way back up passes
-                // (vp-tree.cc:152) and no centre is closer (:154): the lane jumps straight back to
-                // `ret_node` (or is done) instead of climbing level by level.
-                int ret_node = -1, top = t.root;
-                float chain_lb = __int_as_float(0x7f800000), chain_d2 = chain_lb;
+                // `chain_m` is a lower bound of min(|radius - d|, d) over its nodes.  If the bucket
+                // at its end answers with a distance below it, every prune test on the way back up
+                // passes (vp-tree.cc:152) and no centre is closer (:154): the lane jumps straight
+                // back to `ret_node` (or is done) instead of climbing level by level.
+                // If the answer is below the second smallest only, exactly one level (`arg`) can
+                // matter: the lane goes there, and from there back to `ret_node`.
+                int ret_node = -1, top = t.root, arg = -1;
+                float chain_m = __int_as_float(0x7f800000), chain_m2 = chain_m;
                 uint32_t sp = 0, ovf = 0;
                 uint32_t n_int = 0, n_pts = 0; // work counters of this query
                 float rd = 0.f;
@@ -556,9 +571,9 @@ namespace icp_dev
                             const float d2 = sq_dist(qx, qy, qz, N.cx, N.cy, N.cz);
                             const float da = __builtin_amdgcn_sqrtf(d2); // as in the general step
                             const float lb = __fsub_rn(
-                                fabsf(__fsub_rn(N.r, da)),
+                                fminf(fabsf(__fsub_rn(N.r, da)), da),
                                 __fadd_rn(__fmul_rn(__fadd_rn(da, N.r), 0x1p-20f), 1e-18f));
-                            chain_min(chain_lb, chain_d2, lb, d2);
+                            chain_track(chain_m, chain_m2, arg, lb, node);
                             const int go = d2 < N.thr ? N.inside : N.outside; // :147-148
                             if (go >= 0)
                                 node = go;
@@ -614,9 +629,9 @@ namespace icp_dev
                                 // sends the lane the long way round
                                 const float da = __builtin_amdgcn_sqrtf(d2);
                                 const float lb = __fsub_rn(
-                                    fabsf(__fsub_rn(N.r, da)),
+                                    fminf(fabsf(__fsub_rn(N.r, da)), da),
                                     __fadd_rn(__fmul_rn(__fadd_rn(da, N.r), 0x1p-20f), 1e-18f));
-                                chain_min(chain_lb, chain_d2, lb, d2);
+                                chain_track(chain_m, chain_m2, arg, lb, node);
                             }
                             const int nearc = in_near ? N.inside : N.outside;
                             const int farc = in_near ? N.outside : N.inside;
@@ -626,22 +641,32 @@ namespace icp_dev
                             {
                                 const float d = sqrtf(d2); // only the way up compares distances
                                 bool up;
-                                if (prev == nearc)
+                                // (a lane that jumped here from its bucket came up the near side)
+                                const bool marked = prev == kNearMark;
+                                bool done_after = false;
+                                if (prev == nearc || marked)
                                 {
                                     // back from the near side (:152)
                                     if (rd < fabsf(__fsub_rn(N.r, d)))
                                         up = true;
                                     else
                                     {
+                                        // the one level that matters on the chain from the root:
+                                        // once its far side is searched the lane is done, noted
+                                        // in the sign of the distance parked here (distances are
+                                        // >= 0; -0.0 carries the sign too)
+                                        const float parked =
+                                            (marked && ret_node < 0) ? __uint_as_float(__float_as_uint(rd) | 0x80000000u)
+                                                                     : rd;
                                         if (sp < (uint32_t)kStackK)
                                         {
-                                            st_d[sp * kWave] = rd;
+                                            st_d[sp * kWave] = parked;
                                             st_i[sp * kWave] = rid;
                                         }
                                         else
                                         {
                                             spill_col[(sp - kStackK) * spill_stride] =
-                                                make_uint2(__float_as_uint(rd), rid);
+                                                make_uint2(__float_as_uint(parked), rid);
                                             ovf += 1u;
                                         }
                                         sp += 1u;
@@ -649,7 +674,7 @@ namespace icp_dev
                                         up = false;
                                         ret_node = node; // a new chain starts at the far child
                                         top = farc;
-                                        chain_lb = chain_d2 = __int_as_float(0x7f800000);
+                                        chain_m = chain_m2 = __int_as_float(0x7f800000);
                                     }
                                 }
                                 else
@@ -669,6 +694,8 @@ namespace icp_dev
                                         nd = __uint_as_float(e.x);
                                         ni = e.y;
                                     }
+                                    done_after = (__float_as_uint(nd) >> 31) != 0u;
+                                    nd = fabsf(nd);
                                     if (!(rd < nd))
                                     {
                                         rd = nd;
@@ -684,8 +711,10 @@ namespace icp_dev
                                         rd = d;
                                         rid = t.n_slots + (uint32_t)node;
                                     }
-                                    prev = node;
-                                    node = N.parent;
+                                    // nothing between this level and where the chain began can
+                                    // change the answer (marked), nor anything above it (done_after)
+                                    prev = marked ? top : node;
+                                    node = done_after ? -1 : marked ? ret_node : N.parent;
                                     mode = node < 0 ? tDone : tReturn;
                                 }
                             }
@@ -814,11 +843,15 @@ namespace icp_dev
                         {
                             rd = r;
                             rid = win;
-                            // r * r is within 2 ulps of every d2 whose root is r
-                            if (r < chain_lb && chain_d2 > __fmul_rn(__fmul_rn(r, r), 1.000002f))
+                            if (r < chain_m)
                             {
                                 node = ret_node;
                                 prev = top;
+                            }
+                            else if (r < chain_m2)
+                            {
+                                node = arg;
+                                prev = kNearMark;
                             }
                             mode = node < 0 ? tDone : tReturn;
                         }
@@ -827,12 +860,15 @@ namespace icp_dev
                     {
                         const float m = rd; // squared distance of the bucket's answer
                         rd = sqrtf(m);
-                        // no centre of the chain is strictly closer: d2_k > m (1 + 1e-6) gives
-                        // sqrtf(d2_k) >= sqrtf(m)
-                        if (rd < chain_lb && chain_d2 > __fmul_rn(m, 1.000001f))
+                        if (rd < chain_m)
                         {
                             node = ret_node;
                             prev = top;
+                        }
+                        else if (rd < chain_m2)
+                        {
+                            node = arg; // the one level that can matter
+                            prev = kNearMark;
                         }
                         mode = node < 0 ? tDone : tReturn;
                     }
@@ -914,8 +950,23 @@ namespace icp_dev
                     }
                 }
                 cy_tail += now() - cy_e0;
-                if (STATS && lane == 0) // histogram of batch durations, bins of 8192 cycles
-                    atomicAdd(stats + 88 + min(63ull, (now() - cy_b0) >> 13), 1ull);
+                if (STATS && lane == 0)
+                {
+                    // histogram of batch durations (bins of 8192 cycles), and what the batches
+                    // below / from 90112 cycles (11 bins) were made of
+                    const unsigned long long dur = now() - cy_b0;
+                    atomicAdd(stats + 88 + min(63ull, dur >> 13), 1ull);
+                    unsigned long long* cls = stats + 152 + (dur >= (11ull << 13) ? 9 : 0);
+                    atomicAdd(cls + 0, 1ull);
+                    atomicAdd(cls + 1, dur);
+                    atomicAdd(cls + 2, cy_node - cy_node_b0);
+                    atomicAdd(cls + 3, cy_tile - cy_tile_b0);
+                    atomicAdd(cls + 4, (cy_coop - cy_coop_b0) - (cy_tile - cy_tile_b0));
+                    atomicAdd(cls + 5, (unsigned long long)(st_node - st_node_b0));
+                    atomicAdd(cls + 6, (unsigned long long)(st_leafph - st_leafph_b0));
+                    atomicAdd(cls + 7, (unsigned long long)(st_tile - st_tile_b0));
+                    atomicAdd(cls + 8, (unsigned long long)(st_coop - st_coop_b0));
+                }
             }
                 if (chunk_sums && lane_c < (uint32_t)kCovSums)
                     chunk_sums[(size_t)chunk * kCovSums + lane_c] = L.sums[lane_c];

@@ -1,12 +1,15 @@
 // Host emulation of the NN kernel's way back up the tree (development tool, not product code):
 //   plain   every level is stepped (the reference's recursion, vp-tree.cc:125-175);
-//   chain   the kernel: if the bucket's answer is below the descent chain's bound the lane
+//   chain   the kernel before: if the bucket's answer is below the descent chain's bound the lane
 //           jumps back to where the descent began, else it climbs level by level;
 //   heap    a scheme that was built, measured and dropped ("tried and
 //           dropped"): internal nodes are in heap order (children of i are 2i+1 / 2i+2), the
 //           descent marks in a bit mask the levels whose tests could fail for an answer <= G (a
 //           per-batch guess), and the way up visits only those by ancestor arithmetic.
-// Checks that all three give the same answer for every query and prints, per 64-query batch in
+//   single  the kernel now: chain + "exactly one level of the descent can matter" (the answer is
+//           below the second smallest bound of the chain): the lane goes to that level, takes its
+//           real step, and jumps from there back to where the descent began.
+// Checks that all of them give the same answer for every query and prints, per 64-query batch in
 // leaf order, the number of lock-step "general steps" (max over the batch's lanes) of each scheme.
 // build: g++ -O2 -fopenmp -Iinclude scripts/emulate_level_skip.cc -Licp_amd/lib -licp_hip \
 //            -Wl,-rpath,$PWD/icp_amd/lib -o /tmp/emu_skip
@@ -59,8 +62,10 @@ namespace
     {
         PLAIN,
         CHAIN,
-        HEAP
+        HEAP,
+        SINGLE // chain + "exactly one level of the descent can matter": go there, then back to the start
     };
+    constexpr int32_t kNearMark = INT32_MIN; // `prev` of a lane that jumped to the one level
 
     void leaf_scan(const icp_flat_tree* t, float qx, float qy, float qz, uint32_t lbeg, uint32_t lcnt,
                    float& rd, uint32_t& rid)
@@ -102,6 +107,11 @@ namespace
         // chain scheme
         int32_t ret_node = -1, top = t->root;
         float chain_lb = INFINITY, chain_d2 = INFINITY;
+        // single scheme: smallest and second smallest of min(|radius - d|, d) - slack, and the node
+        // of the smallest
+        float chain_m = INFINITY, chain_m2 = INFINITY;
+        int32_t arg = -1;
+        std::vector<uint8_t> st_flag; // pushed with the near answer: "done after this far search"
         // heap scheme
         uint32_t mask = 0, origins = 0;
         Result R{0, 0.f, 0, 0, 0.f};
@@ -158,6 +168,20 @@ namespace
                     }
                     mode = node < 0 ? DONE : RET;
                 }
+                else if (scheme == SINGLE)
+                {
+                    if (rd < chain_m)
+                    {
+                        node = ret_node;
+                        prev = top;
+                    }
+                    else if (rd < chain_m2)
+                    {
+                        node = arg;
+                        prev = kNearMark;
+                    }
+                    mode = node < 0 ? DONE : RET;
+                }
                 else if (scheme == HEAP)
                 {
                     R.gmax = std::fmax(R.gmax, origins ? rd * far_w : rd);
@@ -197,13 +221,28 @@ namespace
                     const bool skip = (G < lb) && (d2 > G2);
                     mask |= skip ? 0u : bit;
                 }
+                else if (scheme == SINGLE)
+                {
+                    const float slack = (d + rad) * 0x1p-20f + 1e-18f;
+                    const float m = std::fmin(std::fabs(rad - d), d) - slack;
+                    if (m < chain_m)
+                    {
+                        chain_m2 = chain_m;
+                        chain_m = m;
+                        arg = node;
+                    }
+                    else
+                        chain_m2 = std::fmin(chain_m2, m);
+                }
             }
             int32_t go = nearc;
             bool down = true;
             if (mode == RET)
             {
                 bool up;
-                if (prev == nearc)
+                const bool marked = prev == kNearMark;
+                bool done_after = false;
+                if (prev == nearc || marked)
                 {
                     if (rd < std::fabs(rad - d))
                         up = true;
@@ -211,8 +250,17 @@ namespace
                     {
                         st_d.push_back(rd);
                         st_i.push_back(rid);
+                        // the one level that matters, on the chain from the root: nothing above it
+                        // can change the answer, so the lane is done once this far side is searched
+                        st_flag.push_back(marked && ret_node < 0);
                         go = farc;
                         up = false;
+                        if (scheme == SINGLE)
+                        {
+                            ret_node = node;
+                            top = farc;
+                            chain_m = chain_m2 = INFINITY;
+                        }
                         if (scheme == CHAIN)
                         {
                             ret_node = node;
@@ -231,8 +279,10 @@ namespace
                 {
                     const float nd = st_d.back();
                     const uint32_t ni = st_i.back();
+                    done_after = st_flag.back() != 0;
                     st_d.pop_back();
                     st_i.pop_back();
+                    st_flag.pop_back();
                     if (!(rd < nd))
                     {
                         rd = nd;
@@ -254,6 +304,22 @@ namespace
                         mask &= ~bit;
                         origins &= ~bit;
                         heap_jump();
+                    }
+                    else if (scheme == SINGLE && (marked || done_after))
+                    {
+                        // back to where this chain began (marked), or done (after the far side of
+                        // the one level of the root chain)
+                        if (done_after)
+                        {
+                            prev = node;
+                            node = -1;
+                        }
+                        else
+                        {
+                            node = ret_node;
+                            prev = top;
+                        }
+                        mode = node < 0 ? DONE : RET;
                     }
                     else
                     {
@@ -354,13 +420,14 @@ int main(int argc, char** argv)
     const uint64_t per_wave = 64;
     uint64_t steps_plain = 0, steps_chain = 0, steps_heap = 0, lanes_invalid = 0, mismatches = 0;
     uint64_t lane_steps_plain = 0, lane_steps_chain = 0, lane_steps_heap = 0;
-#pragma omp parallel for schedule(dynamic, 4) reduction(+ : steps_plain, steps_chain, steps_heap, lanes_invalid, mismatches, lane_steps_plain, lane_steps_chain, lane_steps_heap)
+    uint64_t steps_single = 0, lane_steps_single = 0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : steps_plain, steps_chain, steps_heap, lanes_invalid, mismatches, lane_steps_plain, lane_steps_chain, lane_steps_heap, steps_single, lane_steps_single)
     for (uint64_t w0 = 0; w0 < n_batches; w0 += per_wave)
     {
         float G = INFINITY;
         for (uint64_t b = w0; b < std::min(n_batches, w0 + per_wave); ++b)
         {
-            uint32_t mp = 0, mc = 0, mh = 0;
+            uint32_t mp = 0, mc = 0, mh = 0, ms_ = 0;
             float gmax = 0.f;
             for (uint64_t k = b * 64; k < std::min<uint64_t>(n, b * 64 + 64); ++k)
             {
@@ -369,6 +436,11 @@ int main(int argc, char** argv)
                 const Result p = walk(t, qx, qy, qz, PLAIN, 0.f, 0.f);
                 const Result c = walk(t, qx, qy, qz, CHAIN, 0.f, 0.f);
                 const Result h = walk(t, qx, qy, qz, HEAP, G, far_w);
+                const Result sg = walk(t, qx, qy, qz, SINGLE, 0.f, 0.f);
+                if (p.rid != sg.rid || std::memcmp(&p.rd, &sg.rd, 4) || p.n_int != sg.n_int)
+                    mismatches += 1;
+                ms_ = std::max(ms_, sg.steps);
+                lane_steps_single += sg.steps;
                 if (p.rid != c.rid || p.rid != h.rid || std::memcmp(&p.rd, &c.rd, 4) ||
                     std::memcmp(&p.rd, &h.rd, 4) || p.n_int != c.n_int || p.n_int != h.n_int)
                     mismatches += 1;
@@ -384,13 +456,15 @@ int main(int argc, char** argv)
             steps_plain += mp;
             steps_chain += mc;
             steps_heap += mh;
+            steps_single += ms_;
             G = gmax * g_factor;
         }
     }
     std::printf("mismatches %llu\n", (unsigned long long)mismatches);
-    std::printf("general steps per batch (max over lanes): plain %.2f chain %.2f heap %.2f\n",
+    std::printf("general steps per batch (max over lanes): plain %.2f chain %.2f heap %.2f single %.2f\n",
                 (double)steps_plain / n_batches, (double)steps_chain / n_batches,
-                (double)steps_heap / n_batches);
+                (double)steps_heap / n_batches, (double)steps_single / n_batches);
+    std::printf("general steps per lane: single %.2f\n", (double)lane_steps_single / n);
     std::printf("general steps per lane: plain %.2f chain %.2f heap %.2f   final answer above G: %.4f of lanes\n",
                 (double)lane_steps_plain / n, (double)lane_steps_chain / n, (double)lane_steps_heap / n,
                 (double)lanes_invalid / n);
