@@ -258,6 +258,7 @@ struct icp_hip_ctx
     DevBuf<uint2> leaf_info;
     DevBuf<float> sx, sy, sz;
     DevBuf<uint32_t> srow, nrow;
+    DevBuf<uint32_t> ring; // DevTree::ring (kernels.hh), when every bucket has <= 256 points
     DevBuf<unsigned char> tree_blob; // a small tree: all of the above in one block, one upload
     std::vector<unsigned char> tree_blob_host; // its host image (kept until the next upload)
     uint32_t n_leaves = 0;
@@ -557,6 +558,9 @@ namespace
                     std::fprintf(stderr, " %llu", h[at + b]);
                 std::fprintf(stderr, "\n");
             };
+            std::fprintf(stderr,
+                         "[tile stats] ring walks %llu over %llu lanes, %llu finished by them, %llu wave cycles\n",
+                         h[170], h[171], h[172], h[173]);
             histogram("wave lifetimes", 24, 17);
             histogram("batch durations", 88, 13);
             for (int k = 0; k < 2; ++k)
@@ -841,7 +845,9 @@ namespace
                          o_sx = o_leaf + up8(nl * sizeof(uint2)),
                          o_sy = o_sx + up8((ns + slack) * 4), o_sz = o_sy + up8((ns + slack) * 4),
                          o_srow = o_sz + up8((ns + slack) * 4), o_nrow = o_srow + up8(ns * 4),
-                         total = o_nrow + up8((nn ? nn : 1) * 4);
+                         o_ring = o_nrow + up8((nn ? nn : 1) * 4),
+                         total = o_ring + up8((ns + slack) * 4);
+            const bool with_ring = nn > 0 && t->max_leaf_count <= 256;
             std::vector<unsigned char>& h = c->tree_blob_host;
             try
             {
@@ -891,6 +897,38 @@ namespace
             std::memcpy(h.data() + o_srow, t->slot_row, ns * sizeof(uint32_t));
             if (nn)
                 std::memcpy(h.data() + o_nrow, t->node_row, nn * sizeof(uint32_t));
+            if (with_ring)
+            {
+                // the ring order of the buckets (kernels.hh, DevTree::ring), as ring_build_kernel makes it
+                uint32_t* hr = reinterpret_cast<uint32_t*>(h.data() + o_ring);
+                std::vector<uint32_t> keys;
+                auto bucket = [&](int32_t code, size_t parent) {
+                    if (code >= 0)
+                        return;
+                    const size_t l = (size_t)~code;
+                    const uint32_t beg = t->leaf_begin[l], cnt = t->leaf_count[l];
+                    keys.resize(cnt);
+                    for (uint32_t j = 0; j < cnt; ++j)
+                    {
+                        const float dx = t->slot_x[beg + j] - t->node_cx[parent],
+                                    dy = t->slot_y[beg + j] - t->node_cy[parent],
+                                    dz = t->slot_z[beg + j] - t->node_cz[parent];
+                        const float rho = std::sqrt(dx * dx + dy * dy + dz * dz);
+                        uint32_t bits;
+                        std::memcpy(&bits, &rho, 4);
+                        keys[j] = (bits & 0xFFFFFF00u) | j;
+                    }
+                    std::sort(keys.begin(), keys.end());
+                    const uint32_t padded = (cnt + 15u) & ~15u;
+                    for (uint32_t j = 0; j < padded; ++j)
+                        hr[beg + j] = j < cnt ? keys[j] : 0x7f800000u;
+                };
+                for (size_t i = 0; i < nn; ++i)
+                {
+                    bucket(t->node_inside[i], i);
+                    bucket(t->node_outside[i], i);
+                }
+            }
             HIP_TRY(c, c->tree_blob.alloc(total));
             HIP_TRY(c, hipMemcpyAsync(c->tree_blob.p, h.data(), total, hipMemcpyHostToDevice,
                                       c->stream));
@@ -901,6 +939,7 @@ namespace
             c->sz.release();
             c->srow.release();
             c->nrow.release();
+            c->ring.release();
             unsigned char* b = c->tree_blob.p;
             c->tree.nodes = reinterpret_cast<const DevNode*>(b + o_nodes);
             c->tree.leaf_info = reinterpret_cast<const uint2*>(b + o_leaf);
@@ -909,6 +948,7 @@ namespace
             c->tree.sz = reinterpret_cast<const float*>(b + o_sz);
             c->tree.srow = reinterpret_cast<const uint32_t*>(b + o_srow);
             c->tree.nrow = reinterpret_cast<const uint32_t*>(b + o_nrow);
+            c->tree.ring = with_ring ? reinterpret_cast<const uint32_t*>(b + o_ring) : nullptr;
             c->tree.n_slots = (uint32_t)ns;
             c->tree.n_nodes = (uint32_t)nn;
             c->tree.root = t->root;
@@ -976,12 +1016,6 @@ namespace
         else
             ok = ok && up_slots(c->sx, t->slot_x) && up_slots(c->sy, t->slot_y) &&
                  up_slots(c->sz, t->slot_z) && up(c->srow, t->slot_row, ns);
-        if (ok)
-            ok = (e = hipStreamSynchronize(c->stream)) == hipSuccess;
-        cleanup();
-        if (!ok)
-            return hip_fail(c, e, "icp_hip_set_tree upload");
-
         c->tree.nodes = c->nodes.p;
         c->tree.leaf_info = c->leaf_info.p;
         c->tree.sx = c->sx.p;
@@ -989,7 +1023,32 @@ namespace
         c->tree.sz = c->sz.p;
         c->tree.srow = c->srow.p;
         c->tree.nrow = c->nrow.p;
+        c->tree.ring = nullptr;
         c->tree.n_slots = (uint32_t)ns;
+        c->tree.n_nodes = (uint32_t)nn;
+        // the ring order of the buckets (kernels.hh, DevTree::ring)
+        DevBuf<int32_t> leaf_parent;
+        c->ring.release();
+        if (ok && nn > 0 && t->max_leaf_count <= 256)
+        {
+            ok = (e = c->ring.alloc(ns + slack)) == hipSuccess &&
+                 (e = leaf_parent.alloc(nl)) == hipSuccess &&
+                 (e = hipMemsetAsync(c->ring.p + ns, 0x7f, slack * sizeof(uint32_t), c->stream)) == hipSuccess &&
+                 (e = launch_ring_build(c->tree, (uint32_t)nl, leaf_parent.p, c->ring.p, c->stream)) ==
+                     hipSuccess;
+            if (ok)
+                c->tree.ring = c->ring.p;
+        }
+        if (ok)
+            ok = (e = hipStreamSynchronize(c->stream)) == hipSuccess;
+        leaf_parent.release();
+        cleanup();
+        if (!ok)
+        {
+            c->tree.ring = nullptr;
+            return hip_fail(c, e, "icp_hip_set_tree upload");
+        }
+
         c->tree.n_nodes = (uint32_t)nn;
         c->tree.root = t->root;
         c->height = t->height;
@@ -1544,6 +1603,7 @@ extern "C"
         c->sz.release();
         c->srow.release();
         c->nrow.release();
+        c->ring.release();
         c->px.release();
         c->py.release();
         c->pz.release();

@@ -26,6 +26,14 @@ namespace icp_dev
         const float* sz;
         const uint32_t* srow;
         const uint32_t* nrow; // row of each internal node's centre
+        // The "ring order" of every bucket, or null (no internal node, or a bucket > 256 points):
+        // word k of a bucket's slot range = its point with the k-th smallest distance rho to the
+        // centre of the bucket's PARENT node, as (bits of rho with the low 8 mantissa bits
+        // cleared) | (slot of the point inside the bucket); +inf behind the bucket's points.  A
+        // query at distance d from that centre is at least |rho - d| from the point (triangle
+        // inequality), so a scan that starts at rho = d and walks outwards can stop as soon as the
+        // gap exceeds the best distance found (nn_tile.hip, ring_walk).
+        const uint32_t* ring;
         uint32_t n_slots;
         uint32_t n_nodes;
         int32_t root;
@@ -104,7 +112,7 @@ namespace icp_dev
     // kTileStatsWords counters (workgroup b adds to copy b % 64; the host adds the copies up):
     // thousands of waves flushing ~40 counters each to ONE set of words at the end of a pass held
     // up the memory accesses of the waves still working by ~0.9 ms.
-    constexpr int kTileStatsWords = 24 + 64 + 64 + 18;
+    constexpr int kTileStatsWords = 24 + 64 + 64 + 18 + 6;
     constexpr int kTileStatsCopies = 64;
     struct TileLaunch
     {
@@ -213,6 +221,10 @@ namespace icp_dev
     hipError_t launch_scatter_aos(const float* x, const float* y, const float* z,
                                   const uint32_t* perm, uint32_t n, float* aos, hipStream_t s);
 
+    // ring order of the buckets (DevTree::ring): t.ring is ignored, `ring` (n_slots words) is written;
+    // leaf_parent is scratch of n_leaves words.  Needs n_nodes >= 1 and every bucket <= 256 points.
+    hipError_t launch_ring_build(const DevTree& t, uint32_t n_leaves, int32_t* leaf_parent,
+                                 uint32_t* ring, hipStream_t s);
     hipError_t launch_pack_nodes(const float* cx, const float* cy, const float* cz, const float* r,
                                  const int32_t* inside, const int32_t* outside,
                                  const int32_t* parent, uint32_t n, DevNode* out, hipStream_t s);

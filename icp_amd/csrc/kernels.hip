@@ -433,6 +433,76 @@ namespace icp_dev
         }
     }
 
+    // ---- ring order of the buckets (DevTree::ring) ----
+    __global__ void __launch_bounds__(kBlock)
+        leaf_parent_kernel(const DevNode* __restrict__ nodes, uint32_t n_nodes,
+                           int32_t* __restrict__ leaf_parent)
+    {
+        for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n_nodes; i += gridDim.x * kBlock)
+        {
+            const DevNode N = nodes[i];
+            if (N.inside < 0)
+                leaf_parent[~N.inside] = (int32_t)i;
+            if (N.outside < 0)
+                leaf_parent[~N.outside] = (int32_t)i;
+        }
+    }
+
+    // One wave per bucket (<= 256 points, 4 per lane): key = (distance to the parent's centre, low
+    // 8 mantissa bits cleared) | slot; the rank of a key among the bucket's keys (they are
+    // distinct: the slot is part of them) is its place in the ring order.
+    __global__ void __launch_bounds__(kBlock)
+        ring_build_kernel(DevTree t, const int32_t* __restrict__ leaf_parent, uint32_t n_leaves,
+                          uint32_t* __restrict__ ring)
+    {
+        __shared__ uint32_t s_keys[kWavesPerBlock][256];
+        const int lane = threadIdx.x & (kWave - 1);
+        const int w = threadIdx.x >> 6;
+        for (uint32_t l = blockIdx.x * kWavesPerBlock + w; l < n_leaves; l += gridDim.x * kWavesPerBlock)
+        {
+            const uint2 li = t.leaf_info[l];
+            const uint32_t beg = li.x, cnt = min(li.y, 256u);
+            const uint32_t padded = (cnt + 15u) & ~15u;
+            const DevNode N = t.nodes[leaf_parent[l]];
+            uint32_t key[4], rank[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+            {
+                const uint32_t slot = 4u * (uint32_t)lane + (uint32_t)c;
+                key[c] = 0x7f800000u;
+                if (slot < cnt)
+                {
+                    const float rho = sqrtf(sq_dist(t.sx[beg + slot], t.sy[beg + slot], t.sz[beg + slot],
+                                                    N.cx, N.cy, N.cz));
+                    key[c] = (__float_as_uint(rho) & 0xFFFFFF00u) | slot;
+                }
+                s_keys[w][slot] = key[c];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (uint32_t j = 0; j < cnt; ++j)
+            {
+                const uint32_t k = s_keys[w][j];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    rank[c] += k < key[c] ? 1u : 0u;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+            {
+                const uint32_t slot = 4u * (uint32_t)lane + (uint32_t)c;
+                if (slot < cnt)
+                    ring[beg + rank[c]] = key[c];
+                else if (slot < padded)
+                    ring[beg + slot] = 0x7f800000u;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier(); // the next bucket overwrites this wave's keys
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+
     // SoA host tree arrays -> packed 32-byte node records.
     __global__ void __launch_bounds__(kBlock)
         pack_nodes_kernel(const float* cx, const float* cy, const float* cz, const float* r,
@@ -578,6 +648,19 @@ namespace icp_dev
     {
         hipLaunchKernelGGL(soa_to_aos_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, s, x, y, z, n,
                            aos);
+        return hipGetLastError();
+    }
+
+    hipError_t launch_ring_build(const DevTree& t, uint32_t n_leaves, int32_t* leaf_parent,
+                                 uint32_t* ring, hipStream_t s)
+    {
+        if (t.n_nodes == 0 || n_leaves == 0)
+            return hipErrorInvalidValue;
+        hipLaunchKernelGGL(leaf_parent_kernel, dim3(stream_grid(t.n_nodes)), dim3(kBlock), 0, s,
+                           t.nodes, t.n_nodes, leaf_parent);
+        const uint32_t blocks = (n_leaves + kWavesPerBlock - 1) / kWavesPerBlock;
+        hipLaunchKernelGGL(ring_build_kernel, dim3(blocks < 8192u ? blocks : 8192u), dim3(kBlock), 0, s,
+                           t, leaf_parent, n_leaves, ring);
         return hipGetLastError();
     }
 

@@ -25,7 +25,14 @@
 //    loads per lane), the g queries are replicated over P = 64 / pow2(g) lane groups, group p
 //    scans part p of the bucket for all g queries (LDS float4 reads, conflict free by
 //    construction), and the partial minima are folded across the groups.  g = 1 degenerates to
-//    the whole wave scanning for one query, g = 64 to one lane per query.
+//    the whole wave scanning for one query, g = 64 to one lane per query;
+//  * before the tile scan every lane of the group tries the RING WALK: the bucket's points are
+//    also listed by their distance to the centre of the bucket's parent node (DevTree::ring), a
+//    query looks up its own distance to that centre in the list and examines the points
+//    outwards from there until the gap to the next ring exceeds the best distance found (the
+//    triangle inequality, one level below the tree).  Once the clouds are aligned it finishes
+//    99.6 % of the lanes after one or two points instead of the bucket's 244; a lane that is not
+//    finished after six points is left to the tile scan (see ring_walk).
 //
 // Exactness of the bucket scan.  The reference keeps the first slot that minimises
 // sqrt(d2) under strict < (vp-tree.cc:131-143), d2 = ((dx*dx)+(dy*dy))+(dz*dz) in fp32 without
@@ -165,6 +172,105 @@ namespace icp_dev
             return v;
         }
 
+        // Stage the window [first, first + cw) of a bucket in the image: x is +inf in every slot
+        // that is not the bucket's.
+        __device__ __forceinline__ void stage_window(const DevTree& t, WaveLds& L, uint32_t first,
+                                                     uint32_t cw, int lane)
+        {
+            const float kInf = __int_as_float(0x7f800000);
+            const uint32_t s0 = 4u * (uint32_t)lane;
+            float4 vx = make_float4(kInf, kInf, kInf, kInf);
+            float4 vy = make_float4(0.f, 0.f, 0.f, 0.f), vz = vy;
+            if (s0 < cw)
+            {
+                const size_t o = (size_t)first + s0;
+                vx = *reinterpret_cast<const float4*>(t.sx + o);
+                vy = *reinterpret_cast<const float4*>(t.sy + o);
+                vz = *reinterpret_cast<const float4*>(t.sz + o);
+                vx.y = (s0 + 1u < cw) ? vx.y : kInf;
+                vx.z = (s0 + 2u < cw) ? vx.z : kInf;
+                vx.w = (s0 + 3u < cw) ? vx.w : kInf;
+            }
+            *reinterpret_cast<float4*>(L.bx + s0) = vx;
+            *reinterpret_cast<float4*>(L.by + s0) = vy;
+            *reinterpret_cast<float4*>(L.bz + s0) = vz;
+        }
+
+        // ---- the ring walk: a bucket scan that starts where the answer must be ----
+        // DevTree::ring (kernels.hh) lists a bucket's points by their distance rho to the centre
+        // of the bucket's parent node.  A query at distance dq from that centre is at least
+        // |rho - dq| from the point, so the lane looks up dq in the list and examines the points
+        // outwards from there, nearest ring first, until the gap to the next ring on either side
+        // exceeds the best distance found: nothing beyond can be as close.  Once the clouds are
+        // aligned that is after one or two points instead of the bucket's 244.  Every lane walks
+        // for its own query (the image and the ring words of the bucket are staged in LDS; the
+        // ring words lie in the query table of the tile scan, which is not in use meanwhile); a
+        // lane that is not finished after kWalkMax points leaves its query to the tile scan.
+        //   Bounds.  Stored: rho_lo = the computed distance with its low 8 mantissa bits cleared,
+        // so the point's real distance lies in [rho_lo (1 - 4e-7), rho_lo (1 + 2^-15) (1 + 4e-7)];
+        // dq is the raw v_sqrt_f32 of the reference's d2 (within 4e-7 of the real distance).  The
+        // gap to a ring above is rho_lo - dq, to a ring below dq - rho_lo (1 + 2^-15), each minus
+        // a slack of 2^-20 (rho + dq), more than twice those errors.  The walk stops when
+        // gap^2 > m1 (1 + 1e-5), m1 the smallest reference d2 found: every point not examined
+        // then has a real squared distance above m1 (1 + 1e-5) and a reference d2 (within 4e-7 of
+        // it) far more than 4 ulps above m1.  Among the points examined the answer is the one of
+        // m1 if the runner-up m2 is more than 4 ulps above it (their roots then round to different
+        // floats, top of the file); otherwise the lane goes to the exact scan, as after a tile scan.
+        constexpr int kWalkMax = 6;
+        __device__ __forceinline__ bool ring_walk(const WaveLds& L, uint32_t cnt, bool active, float qx,
+                                                  float qy, float qz, float dq, float& out_m,
+                                                  uint32_t& out_idx, bool& out_ok)
+        {
+            const float kInf = __int_as_float(0x7f800000);
+            const uint32_t* rw = reinterpret_cast<const uint32_t*>(L.qb); // 256 words, +inf behind cnt
+            // how many rings lie below dq (the list is ascending, +inf padded to 256 words)
+            uint32_t pos = 0;
+#pragma unroll
+            for (uint32_t step = 128u; step >= 1u; step >>= 1)
+            {
+                const float rho = __uint_as_float(rw[pos + step - 1u] & 0xFFFFFF00u);
+                pos += rho < dq ? step : 0u;
+            }
+            int up = (int)pos, dn = (int)pos - 1;
+            float m1 = kInf, m2 = kInf;
+            uint32_t s1 = 0;
+            bool done = !active;
+#pragma nounroll
+            for (int it = 0; it <= kWalkMax; ++it)
+            {
+                if (__ballot(!done) == 0ull)
+                    break;
+                if (!done)
+                {
+                    const uint32_t wu = rw[min(up, 255)], wd = rw[max(dn, 0)];
+                    const float ru = __uint_as_float(wu & 0xFFFFFF00u);
+                    const float rl = __uint_as_float(wd & 0xFFFFFF00u);
+                    const float gu = (uint32_t)up < cnt ? __fsub_rn(ru, dq) : kInf;
+                    const float gd = dn >= 0 ? __fsub_rn(dq, __fadd_rn(rl, __fmul_rn(rl, 0x1p-15f))) : kInf;
+                    const bool take_up = gu <= gd;
+                    const float gap = take_up ? gu : gd;
+                    const float ref = take_up ? ru : rl;
+                    const float g = __fsub_rn(gap, __fadd_rn(__fmul_rn(__fadd_rn(ref, dq), 0x1p-20f), 1e-18f));
+                    if (g > 0.f && __fmul_rn(g, g) > __fmul_rn(m1, 1.00001f))
+                        done = true; // (both sides exhausted: the gap is +inf)
+                    else if (it < kWalkMax)
+                    {
+                        const uint32_t slot = (take_up ? wu : wd) & 0xFFu;
+                        up += take_up ? 1 : 0;
+                        dn -= take_up ? 0 : 1;
+                        const float d2 = sq_dist(qx, qy, qz, L.bx[slot], L.by[slot], L.bz[slot]);
+                        m2 = d2 < m1 ? m1 : fminf(m2, d2);
+                        s1 = d2 < m1 ? slot : s1;
+                        m1 = fminf(m1, d2);
+                    }
+                }
+            }
+            out_m = m1;
+            out_idx = s1;
+            out_ok = (int)(__float_as_uint(m2) - __float_as_uint(m1)) > 4;
+            return active && done;
+        }
+
         // Tile scan of bucket [beg, beg+cnt) for the g lanes in `grp` (all of them wait on it).
         // The 64 lanes form P = 64/g parts of g lanes; lane (part p, slot s) scans the float4
         // groups p, p+P, p+2P, .. of the staged image for the query of rank s.  Inside the loop
@@ -208,22 +314,7 @@ namespace icp_dev
                 if (staged != beg + w0)
                 {
                     staged = beg + w0;
-                    const uint32_t s0 = 4u * (uint32_t)lane;
-                    float4 vx = make_float4(kInf, kInf, kInf, kInf);
-                    float4 vy = make_float4(0.f, 0.f, 0.f, 0.f), vz = vy;
-                    if (s0 < cw)
-                    {
-                        const size_t o = (size_t)beg + w0 + s0;
-                        vx = *reinterpret_cast<const float4*>(t.sx + o);
-                        vy = *reinterpret_cast<const float4*>(t.sy + o);
-                        vz = *reinterpret_cast<const float4*>(t.sz + o);
-                        vx.y = (s0 + 1u < cw) ? vx.y : kInf;
-                        vx.z = (s0 + 2u < cw) ? vx.z : kInf;
-                        vx.w = (s0 + 3u < cw) ? vx.w : kInf;
-                    }
-                    *reinterpret_cast<float4*>(L.bx + s0) = vx;
-                    *reinterpret_cast<float4*>(L.by + s0) = vy;
-                    *reinterpret_cast<float4*>(L.bz + s0) = vz;
+                    stage_window(t, L, beg + w0, cw, lane);
                 }
                 wave_lds_fence();
                 const float4 q = L.qb[slot];
@@ -419,10 +510,11 @@ namespace icp_dev
             }
             // wave-level event counts of the diagnostic build (ICP_HIP_TILE_STATS=1)
             uint32_t st_node = 0, st_tile = 0, st_tile_g = 0, st_tile_len = 0, st_coop = 0,
-                     st_exact = 0, st_leafph = 0, st_batch = 0, st_node_lanes = 0;
+                     st_exact = 0, st_leafph = 0, st_batch = 0, st_node_lanes = 0, st_walk = 0,
+                     st_walk_done = 0, st_walk_lanes = 0;
             // shader cycles by phase (diagnostic build only)
             unsigned long long cy_node = 0, cy_tile = 0, cy_coop = 0, cy_exact = 0, cy_tail = 0,
-                               cy_head = 0, cy_total = 0, cy_pop = 0;
+                               cy_head = 0, cy_total = 0, cy_pop = 0, cy_walk = 0;
             const unsigned long long rt_begin = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
             if (STATS)
                 stats += (size_t)(blockIdx.x % (uint32_t)kTileStatsCopies) * kTileStatsWords;
@@ -444,11 +536,20 @@ namespace icp_dev
             }
             uint32_t staged = 0xFFFFFFFFu; // wave-uniform: window of the bucket image in LDS
             uint32_t staged_cnt = 0;       // wave-uniform: bucket slots in that window
+            uint32_t ring_tag = 0xFFFFFFFFu; // wave-uniform: bucket whose ring words lie in L.qb
+            uint32_t walk_skip = 0;          // wave-uniform: groups to serve without trying the walk
+            uint32_t walk_backoff = 8;       // ... after the next walk that does not pay (doubles)
             int lc_code = 0;               // wave-uniform: child code of the last bucket served
             uint32_t lc_beg = 0, lc_cnt = 0; // (0 is an internal node: matches no leaf) + its entry
             // this lane's column of the overflow stack: entry e at spill_col[e * spill_stride]
+            // (made where it is used, from a thread index the compiler cannot see through: kept
+            // across the kernel the address was one of the registers that spilled to scratch)
             const size_t spill_stride = (size_t)gridDim.x * kBlock;
-            uint2* spill_col = spill + (size_t)blockIdx.x * kBlock + threadIdx.x;
+            auto spill_at = [&](uint32_t e) -> uint2* {
+                uint32_t tid = threadIdx.x;
+                asm volatile("" : "+v"(tid));
+                return spill + ((size_t)blockIdx.x * kBlock + tid + (size_t)e * spill_stride);
+            };
 
             // XCD group x owns chunks [x*per_group, (x+1)*per_group); its head is queue[x*32]
             const uint32_t per_group = (n_chunks + 7u) >> 3;
@@ -665,7 +766,7 @@ namespace icp_dev
                                         }
                                         else
                                         {
-                                            spill_col[(sp - kStackK) * spill_stride] =
+                                            *spill_at(sp - kStackK) =
                                                 make_uint2(__float_as_uint(parked), rid);
                                             ovf += 1u;
                                         }
@@ -690,7 +791,7 @@ namespace icp_dev
                                     }
                                     else
                                     {
-                                        const uint2 e = spill_col[(sp - kStackK) * spill_stride];
+                                        const uint2 e = *spill_at(sp - kStackK);
                                         nd = __uint_as_float(e.x);
                                         ni = e.y;
                                     }
@@ -760,11 +861,86 @@ namespace icp_dev
                         lc_code = __builtin_amdgcn_readlane(prev, l);
                         lc_beg = beg;
                         lc_cnt = cnt;
-                        const bool member = (mode == tWaitLeaf) && (lbeg == beg);
-                        const uint64_t grp = __ballot(member);
+                        bool member = (mode == tWaitLeaf) && (lbeg == beg);
+                        uint64_t grp = __ballot(member);
                         pend &= ~grp;
-                        const int g_all = __builtin_popcountll(grp);
-                        if (g_all >= kTileMinGroup)
+                        int g_all = __builtin_popcountll(grp);
+                        // ---- first the ring walk (see ring_walk): the lanes it finishes leave the
+                        // group, the tile scan below serves the rest ----
+                        if (g_all >= kTileMinGroup && t.ring && cnt <= (uint32_t)kImage)
+                        {
+                            if (walk_skip != 0u)
+                                walk_skip -= 1u;
+                            else
+                            {
+                                const unsigned long long cy_w0 = now();
+                                if (staged != beg)
+                                {
+                                    staged = beg;
+                                    stage_window(t, L, beg, cnt, lane);
+                                }
+                                staged_cnt = cnt;
+                                if (ring_tag != beg)
+                                {
+                                    ring_tag = beg;
+                                    uint32_t s0 = 4u * (uint32_t)lane;
+                                    asm volatile("" : "+v"(s0)); // (the address is made here, not kept)
+                                    uint4 rv = make_uint4(0x7f800000u, 0x7f800000u, 0x7f800000u, 0x7f800000u);
+                                    if (s0 < cnt)
+                                    {
+                                        rv = *reinterpret_cast<const uint4*>(t.ring + (size_t)beg + s0);
+                                        rv.y = (s0 + 1u < cnt) ? rv.y : 0x7f800000u;
+                                        rv.z = (s0 + 2u < cnt) ? rv.z : 0x7f800000u;
+                                        rv.w = (s0 + 3u < cnt) ? rv.w : 0x7f800000u;
+                                    }
+                                    reinterpret_cast<uint4*>(L.qb)[lane] = rv;
+                                }
+                                wave_lds_fence();
+                                // distance to the centre the rings are measured from: the
+                                // bucket's parent, which is the node the lane stands on
+                                float dq = 0.f;
+                                if (member)
+                                {
+                                    const float4 pc = *reinterpret_cast<const float4*>(t.nodes + node); // cx, cy, cz, r
+                                    dq = __builtin_amdgcn_sqrtf(sq_dist(qx, qy, qz, pc.x, pc.y, pc.z));
+                                }
+                                float wm;
+                                uint32_t widx;
+                                bool wok;
+                                const bool walked = ring_walk(L, cnt, member, qx, qy, qz, dq, wm, widx, wok);
+                                wave_lds_fence(); // the tile scan's query table overwrites the ring words
+                                if (walked)
+                                {
+                                    rd = wm;
+                                    rid = beg + widx;
+                                    mode = wok ? tServed : tWaitExact;
+                                    member = false;
+                                }
+                                const uint64_t rest = __ballot(member);
+                                if (STATS)
+                                {
+                                    st_walk += 1u;
+                                    st_walk_done += (uint32_t)(g_all - __builtin_popcountll(rest));
+                                    st_walk_lanes += (uint32_t)g_all;
+                                    cy_walk += now() - cy_w0;
+                                }
+                                // a walk that finishes less than half of its lanes does not pay
+                                // (misaligned clouds): leave it out for the next 8, 16, .. 256 groups
+                                if (2 * __builtin_popcountll(rest) > g_all)
+                                {
+                                    walk_skip = walk_backoff;
+                                    walk_backoff = min(2u * walk_backoff, 256u);
+                                }
+                                else
+                                    walk_backoff = 8u;
+                                grp = rest;
+                                g_all = __builtin_popcountll(rest);
+                            }
+                        }
+                        if (g_all == 0)
+                        {
+                        }
+                        else if (g_all >= kTileMinGroup)
                         {
                             // 33..55 lanes would leave the tile half empty (one part only):
                             // serve the first 32 as two parts, then the rest as their own group
@@ -784,6 +960,7 @@ namespace icp_dev
                                 const unsigned long long cy_t0 = now();
                                 tile_scan(t, L, beg, cnt, sub, mem, qx, qy, qz, lane, m, unique, idx,
                                           staged);
+                                ring_tag = 0xFFFFFFFFu; // (its query table lies where the ring words were)
                                 cy_tile += now() - cy_t0;
                                 staged_cnt = min((uint32_t)kImage, beg + cnt - staged); // slots of the window in LDS
                                 if (STATS)
@@ -1007,6 +1184,10 @@ namespace icp_dev
                 atomicAdd(stats + 14, cy_tail);
                 atomicAdd(stats + 20, rt_end - rt_begin);
                 atomicAdd(stats + 21, cy_pop);
+                atomicAdd(stats + 170, (unsigned long long)st_walk);
+                atomicAdd(stats + 171, (unsigned long long)st_walk_lanes);
+                atomicAdd(stats + 172, (unsigned long long)st_walk_done);
+                atomicAdd(stats + 173, cy_walk);
                 atomicMax(stats + 22, cy_total);
                 atomicMax(stats + 23, (unsigned long long)st_batch);
                 // histogram of wave lifetimes (bins of 131072 cycles); first / last wave to start

@@ -350,6 +350,77 @@ namespace
         return R;
     }
 
+    // ---- the ring walk (nn_tile.hip, ring_walk) with the kernel's arithmetic ----
+    // ring words of one bucket: (rho with the low 8 mantissa bits cleared) | slot, ascending
+    std::vector<uint32_t> ring_words(const icp_flat_tree* t, uint32_t leaf, uint32_t parent)
+    {
+        const uint32_t beg = t->leaf_begin[leaf], cnt = t->leaf_count[leaf];
+        std::vector<uint32_t> w(cnt);
+        for (uint32_t j = 0; j < cnt; ++j)
+        {
+            const float rho = std::sqrt(sqd(t->slot_x[beg + j], t->slot_y[beg + j], t->slot_z[beg + j],
+                                            t->node_cx[parent], t->node_cy[parent], t->node_cz[parent]));
+            uint32_t bits;
+            std::memcpy(&bits, &rho, 4);
+            w[j] = (bits & 0xFFFFFF00u) | j;
+        }
+        std::sort(w.begin(), w.end());
+        return w;
+    }
+    inline float word_rho(uint32_t w)
+    {
+        w &= 0xFFFFFF00u;
+        float f;
+        std::memcpy(&f, &w, 4);
+        return f;
+    }
+    // returns true if the walk finished; m1 = smallest d2 among the points examined, s1 its slot,
+    // ok = the runner-up is more than 4 ulps above
+    bool ring_walk(const icp_flat_tree* t, const std::vector<uint32_t>& rw, uint32_t beg, float qx,
+                   float qy, float qz, float dq, int walk_max, float& m1, uint32_t& s1, bool& ok,
+                   uint32_t& examined)
+    {
+        const uint32_t cnt = (uint32_t)rw.size();
+        uint32_t pos = 0;
+        while (pos < cnt && word_rho(rw[pos]) < dq)
+            ++pos;
+        int up = (int)pos, dn = (int)pos - 1;
+        float m2 = INFINITY;
+        m1 = INFINITY;
+        s1 = 0;
+        examined = 0;
+        bool done = false;
+        for (int it = 0; it <= walk_max && !done; ++it)
+        {
+            const float ru = (uint32_t)up < cnt ? word_rho(rw[up]) : INFINITY;
+            const float rl = dn >= 0 ? word_rho(rw[dn]) : 0.f;
+            const float gu = (uint32_t)up < cnt ? ru - dq : INFINITY;
+            const float gd = dn >= 0 ? dq - (rl + rl * 0x1p-15f) : INFINITY;
+            const bool take_up = gu <= gd;
+            const float gap = take_up ? gu : gd, ref = take_up ? ru : rl;
+            const float g = gap - ((ref + dq) * 0x1p-20f + 1e-18f);
+            if (g > 0.f && g * g > m1 * 1.00001f)
+                done = true;
+            else if (it < walk_max)
+            {
+                const uint32_t slot = (take_up ? rw[up] : rw[dn]) & 0xFFu;
+                up += take_up ? 1 : 0;
+                dn -= take_up ? 0 : 1;
+                const float d2 = sqd(qx, qy, qz, t->slot_x[beg + slot], t->slot_y[beg + slot],
+                                     t->slot_z[beg + slot]);
+                m2 = d2 < m1 ? m1 : std::fmin(m2, d2);
+                s1 = d2 < m1 ? slot : s1;
+                m1 = std::fmin(m1, d2);
+                examined += 1;
+            }
+        }
+        uint32_t b1, b2;
+        std::memcpy(&b1, &m1, 4);
+        std::memcpy(&b2, &m2, 4);
+        ok = (int32_t)(b2 - b1) > 4;
+        return done;
+    }
+
     bool heap_ordered(const icp_flat_tree* t)
     {
         for (uint32_t i = 0; i < t->n_nodes; ++i)
@@ -410,6 +481,51 @@ int main(int argc, char** argv)
             c = d < t->node_radius[c] ? t->node_inside[c] : t->node_outside[c];
         }
         leaf[i] = (uint32_t)~c;
+    }
+    // ---- the ring walk on every query's first bucket against the full scan of that bucket ----
+    if (t->max_leaf_count <= 256 && t->n_nodes > 0)
+    {
+        std::vector<int32_t> parent(t->n_leaves, -1);
+        for (uint32_t i = 0; i < t->n_nodes; ++i)
+        {
+            if (t->node_inside[i] < 0)
+                parent[~t->node_inside[i]] = (int32_t)i;
+            if (t->node_outside[i] < 0)
+                parent[~t->node_outside[i]] = (int32_t)i;
+        }
+        std::vector<std::vector<uint32_t>> rings(t->n_leaves);
+#pragma omp parallel for
+        for (uint32_t l = 0; l < t->n_leaves; ++l)
+            rings[l] = ring_words(t, l, (uint32_t)parent[l]);
+        uint64_t finished = 0, answered = 0, wrong = 0, seen = 0;
+#pragma omp parallel for reduction(+ : finished, answered, wrong, seen)
+        for (uint64_t i = 0; i < n; ++i)
+        {
+            const uint32_t l = leaf[i], beg = t->leaf_begin[l], cnt = t->leaf_count[l];
+            const int32_t pn = parent[l];
+            const float qx = q[3 * i], qy = q[3 * i + 1], qz = q[3 * i + 2];
+            const float dq = std::sqrt(sqd(qx, qy, qz, t->node_cx[pn], t->node_cy[pn], t->node_cz[pn]));
+            float m1, rd;
+            uint32_t s1, rid, ex;
+            bool ok;
+            if (!ring_walk(t, rings[l], beg, qx, qy, qz, dq, 6, m1, s1, ok, ex))
+                continue;
+            finished += 1;
+            seen += ex;
+            if (!ok)
+                continue; // the kernel sends these to the exact scan
+            answered += 1;
+            leaf_scan(t, qx, qy, qz, beg, cnt, rd, rid);
+            const float r1 = std::sqrt(m1);
+            if (rid != beg + s1 || std::memcmp(&rd, &r1, 4))
+                wrong += 1;
+        }
+        std::printf("ring walk (6 points at most): finished %.4f of the scans after %.2f points, "
+                    "answered %.4f, different from the full scan: %llu\n",
+                    (double)finished / n, finished ? (double)seen / finished : 0.0, (double)answered / n,
+                    (unsigned long long)wrong);
+        if (wrong)
+            return 1;
     }
     std::vector<uint32_t> order(n);
     std::iota(order.begin(), order.end(), 0u);

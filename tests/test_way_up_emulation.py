@@ -3,7 +3,12 @@ descent, jump to the one level that can matter, or climb level by level), restat
 scripts/emulate_level_skip.cc and compared, query by query, with the plain climb of
 libcpu/libcpu/vp-tree.cc:125-175: same answer (slot and distance bits) and the same count of
 nodes visited, on a misaligned, a nearly aligned and a noise-level aligned cloud, with buckets
-small enough that far-side searches nest.  The emulation exits non-zero on any mismatch."""
+small enough that far-side searches nest.  The same program runs the kernel's ring walk (the
+bucket scan that starts at the ring of the query's distance to the bucket's parent centre and
+stops when the gap to the next ring exceeds the best distance found; ring_walk in nn_tile.hip,
+with the kernel's arithmetic: ring distances cut to 16 mantissa bits, its slack, its stop rule)
+on every query's first bucket against the full scan of that bucket.  The emulation exits non-zero
+on any mismatch."""
 import os
 import subprocess
 
@@ -42,4 +47,5 @@ def test_every_way_up_gives_the_plain_climbs_answer(exe, args):
     r = subprocess.run([exe, *args], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "mismatches 0" in r.stdout
+    assert "different from the full scan: 0" in r.stdout
     assert "heap-ordered 1" in r.stdout
