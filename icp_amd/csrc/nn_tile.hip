@@ -665,9 +665,33 @@ namespace icp_dev
                             st_node += 1u;
                             st_node_lanes += (uint32_t)__builtin_popcountll(goers);
                         }
+                        // The lanes of a batch are neighbours: most of the way down they stand
+                        // on the SAME node.  Then its record comes through the scalar cache (one
+                        // 32-byte read per wave, constant address space: the tree is never
+                        // written while a pass runs) instead of 64 lanes x 32 bytes through the
+                        // vector memory pipe, which the bucket images need.
+                        const int node0 = __builtin_amdgcn_readlane(node, (int)__builtin_ctzll(goers));
+                        const bool same = __ballot(going && node != node0) == 0ull;
                         if (going)
                         {
-                            const DevNode N = t.nodes[node];
+                            typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+                            typedef const __attribute__((address_space(4))) u4* const_u4;
+                            DevNode N;
+                            if (same)
+                            {
+                                const_u4 rec = (const_u4)(t.nodes + node0);
+                                const u4 lo = rec[0], hi = rec[1];
+                                N.cx = __uint_as_float(lo.x);
+                                N.cy = __uint_as_float(lo.y);
+                                N.cz = __uint_as_float(lo.z);
+                                N.r = __uint_as_float(lo.w);
+                                N.inside = (int)hi.x;
+                                N.outside = (int)hi.y;
+                                N.parent = (int)hi.z;
+                                N.thr = __uint_as_float(hi.w);
+                            }
+                            else
+                                N = t.nodes[node];
                             n_int += 1u;
                             const float d2 = sq_dist(qx, qy, qz, N.cx, N.cy, N.cz);
                             const float da = __builtin_amdgcn_sqrtf(d2); // as in the general step
@@ -898,11 +922,16 @@ namespace icp_dev
                                 wave_lds_fence();
                                 // distance to the centre the rings are measured from: the
                                 // bucket's parent, which is the node the lane stands on
+                                // (one node for the whole group: its record comes through the
+                                // scalar cache, like the first descent's)
                                 float dq = 0.f;
-                                if (member)
                                 {
-                                    const float4 pc = *reinterpret_cast<const float4*>(t.nodes + node); // cx, cy, cz, r
-                                    dq = __builtin_amdgcn_sqrtf(sq_dist(qx, qy, qz, pc.x, pc.y, pc.z));
+                                    typedef float f4 __attribute__((ext_vector_type(4)));
+                                    typedef const __attribute__((address_space(4))) f4* const_f4;
+                                    const int parent = __builtin_amdgcn_readlane(node, l);
+                                    const f4 pc = *(const_f4)(t.nodes + parent); // cx, cy, cz, r
+                                    if (member)
+                                        dq = __builtin_amdgcn_sqrtf(sq_dist(qx, qy, qz, pc.x, pc.y, pc.z));
                                 }
                                 float wm;
                                 uint32_t widx;
