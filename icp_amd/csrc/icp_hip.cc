@@ -847,7 +847,9 @@ namespace
                          o_srow = o_sz + up8((ns + slack) * 4), o_nrow = o_srow + up8(ns * 4),
                          o_ring = o_nrow + up8((nn ? nn : 1) * 4),
                          total = o_ring + up8((ns + slack) * 4);
-            const bool with_ring = nn > 0 && t->max_leaf_count <= 256;
+            // (a walk needs 16 lanes on one bucket: clouds of a few thousand points run in
+            // batches too narrow for that, and ranking their buckets here would only cost time)
+            const bool with_ring = nn > 0 && t->max_leaf_count <= 256 && t->n_points >= 16384;
             std::vector<unsigned char>& h = c->tree_blob_host;
             try
             {

@@ -217,6 +217,7 @@ namespace icp_dev
         // m1 if the runner-up m2 is more than 4 ulps above it (their roots then round to different
         // floats, top of the file); otherwise the lane goes to the exact scan, as after a tile scan.
         constexpr int kWalkMax = 6;
+        constexpr int kWalkMinGroup = 16; // lanes on a bucket from which the walk is tried
         __device__ __forceinline__ bool ring_walk(const WaveLds& L, uint32_t cnt, bool active, float qx,
                                                   float qy, float qz, float dq, float& out_m,
                                                   uint32_t& out_idx, bool& out_ok)
@@ -891,7 +892,9 @@ namespace icp_dev
                         int g_all = __builtin_popcountll(grp);
                         // ---- first the ring walk (see ring_walk): the lanes it finishes leave the
                         // group, the tile scan below serves the rest ----
-                        if (g_all >= kTileMinGroup && t.ring && cnt <= (uint32_t)kImage)
+                        // (a small group's tile scan is a few steps long -- 64 / g parts share the
+                        // bucket -- and costs less than a walk)
+                        if (g_all >= kWalkMinGroup && t.ring && cnt <= (uint32_t)kImage)
                         {
                             if (walk_skip != 0u)
                                 walk_skip -= 1u;
