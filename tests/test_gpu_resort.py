@@ -120,3 +120,29 @@ def test_many_rank_rule_decides_from_nothing_a_single_rank_sees(monkeypatch, wor
     assert np.abs(res["0"][0] - res["g"][0]).max() <= 2e-7
     assert np.abs(res["0"][2] - res["g"][2]).max() <= 1e-6
     assert np.median(res["g"][3][-4:]) < np.median(res["0"][3][-4:])
+
+
+def test_host_and_device_loops_agree_across_the_pass_on_a_large_shard(monkeypatch):
+    """8M points: the shard is large enough for chunks of two batches, which become chunks of
+    eight after the second ordering pass (icp_hip.cc, maybe_resort).  The host-driven and the
+    device-resident loop take the pass at the same iteration and change the chunks alike: same
+    bits in the transform, the moved cloud and the error."""
+    from icp_amd import capi, synth
+    n = 8_000_000
+    m = synth.cloud(n, seed=21)
+    mu_m = capi.mean_host(m)
+    mc = capi.center_host(m, mu_m)
+    p = synth.apply_fp32(m, synth.ground_truth(0.5))
+    monkeypatch.delenv("ICP_HIP_RESORT", raising=False)
+    res = []
+    for mode in ("device", "host"):
+        monkeypatch.setenv("ICP_HIP_LOOP", mode)
+        with capi.Context() as ctx:
+            ctx.build_tree(mc, 256)
+            ctx.set_queries(p)
+            T, it, err = ctx.run(mu_m, 14, 0.0)
+            res.append((T.copy(), it, err, ctx.get_points()))
+    assert res[0][1] == res[1][1] == 14 and res[0][2] == res[1][2]
+    assert (bits(res[0][0]) == bits(res[1][0])).all()
+    assert (bits(res[0][3]) == bits(res[1][3])).all()
+    assert np.abs(res[0][0].astype(np.float64) - synth.expected_transform(0.5)).max() < 1e-5
