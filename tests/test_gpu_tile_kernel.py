@@ -193,3 +193,29 @@ def test_queries_a_few_ulps_from_tree_points(oracle, ulps):
     _same(_nn(capi, tree, q, zero), want)
     _same(_nn(capi, tree, q, zero, {"ICP_HIP_NN_KERNEL": "deep"}), want)
     tree.close()
+
+
+@pytest.mark.parametrize("noise", [2e-6, 1e-4, 0.0])
+def test_ring_walk_with_many_queries_per_bucket(oracle, noise):
+    """The ring walk (nn_tile.hip, ring_walk) needs 16 lanes on one bucket: several queries per
+    tree point, at noise level (the walk finishes after a point or two), a ring spacing away (it
+    often does not, and the tile scan takes over) and exactly ON the tree points (distance 0 and
+    duplicates of the query: the isolation test sends them to the exact scan).  The tree is small
+    enough to go up as one host-packed block, whose ring words the host ranks (icp_hip.cc)."""
+    from icp_amd import capi
+    from icp_amd import synth
+    n, reps = 100_000, 8
+    rng = np.random.default_rng(5)
+    m = synth.cloud(n, seed=n)
+    mc = capi.center_host(m, capi.mean_host(m))
+    p = np.tile(mc, (reps, 1)) + rng.normal(0, noise, size=(n * reps, 3)).astype(np.float32)
+    p = np.ascontiguousarray(p[rng.permutation(len(p))].astype(np.float32))
+    zero = np.zeros(3, np.float32)
+    tree = capi.FlatTree(mc, 256)
+    got = _nn(capi, tree, p, zero)
+    sub = rng.permutation(len(p))[:60_000]
+    want = oracle.tree_closest(oracle.tree_build(256, mc), p[sub])
+    assert (got["row"][sub] == want["row"]).all()
+    assert (bits(got["dist"][sub]) == bits(want["dist"])).all()
+    assert (bits(got["xyz"][sub]) == bits(want["xyz"])).all()
+    tree.close()
