@@ -183,4 +183,32 @@ namespace icp_dev
         }
     }
 
+    // out[k] = sum over rows of rows[b*K + k] in a fixed order, by one workgroup of 256 threads:
+    // thread = (row lane, column), 16 x 16 for K <= 16 and 64 x 4 for K <= 4; `s` is
+    // kSumRowsLds doubles of LDS.
+    constexpr int kSumRowsLds = 64 * 5;
+    __device__ __forceinline__ void block_sum_rows(const double* rows, uint32_t n_rows, int K,
+                                                   double* out, double* s)
+    {
+        const int cw = K <= 4 ? 4 : 16;        // columns per row lane group
+        const int lanes = (int)kBlock / cw;    // row lanes
+        const int col = threadIdx.x % cw, rl = threadIdx.x / cw;
+        double v = 0.0;
+        if (col < K)
+        {
+            for (uint32_t r = rl; r < n_rows; r += lanes)
+                v += rows[(size_t)r * K + col];
+        }
+        s[rl * (cw + 1) + col] = v;
+        __syncthreads();
+        if (threadIdx.x < (uint32_t)K)
+        {
+            double tot = 0.0;
+            for (int j = 0; j < lanes; ++j)
+                tot += s[j * (cw + 1) + threadIdx.x];
+            out[threadIdx.x] = tot;
+        }
+        __syncthreads();
+    }
+
 } // namespace icp_dev

@@ -355,24 +355,8 @@ namespace icp_dev
     {
         if (loop && loop->done)
             return; // an iteration enqueued past the end of the device-resident loop
-        __shared__ double s[kBlock];
-        for (int k = 0; k < K; ++k)
-        {
-            double v = 0.0;
-            for (uint32_t b = threadIdx.x; b < nblocks; b += kBlock)
-                v += partials[(size_t)b * K + k];
-            s[threadIdx.x] = v;
-            __syncthreads();
-            for (int off = kBlock / 2; off > 0; off >>= 1)
-            {
-                if ((int)threadIdx.x < off)
-                    s[threadIdx.x] += s[threadIdx.x + off];
-                __syncthreads();
-            }
-            if (threadIdx.x == 0)
-                out[k] = s[0];
-            __syncthreads();
-        }
+        __shared__ double s[kSumRowsLds];
+        block_sum_rows(partials, nblocks, K, out, s);
         // device-resident loop without a collective in between: the scalar step that consumes
         // these sums runs here instead of in a launch of its own (loop_steps.hh)
         if (threadIdx.x == 0 && loop)

@@ -1187,7 +1187,7 @@ namespace icp_dev
             __syncthreads();
             if (threadIdx.x == 0)
             {
-                const uint32_t finished = __hip_atomic_fetch_add(queue + 256, 1u, __ATOMIC_ACQ_REL,
+                const uint32_t finished = __hip_atomic_fetch_add(queue + 256, 1u, __ATOMIC_RELAXED,
                                                                  __HIP_MEMORY_SCOPE_AGENT);
                 if (finished == gridDim.x - 1u)
                 {
