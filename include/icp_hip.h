@@ -168,7 +168,9 @@ int icp_hip_set_queries(icp_hip_ctx* ctx, const float* xyz_aos, uint64_t n_local
 /* One batch nearest-neighbour pass over the shard: query_i = p_i - mu_p.
  * Replaces GPUVPTree::closest / closest_kernel (libgpu/libgpu/vp-tree.cu:181-261), with the
  * CPU rules of VPTree::search (libcpu/libcpu/vp-tree.cc:125-175).
- * Outputs are host arrays of n_local entries and may each be NULL:
+ * Outputs are host arrays of n_local entries and may each be NULL (a NULL row_out / dist_out is
+ * not computed on the device either: those two go back to the caller's order with scattered
+ * stores, which cost as much as the search itself on a large shard):
  *   row_out   row (in the tree's cloud) of the point the reference search returns
  *   xyz_out   that point's coordinates (what VPTree::closest returns, vp-tree.cc:177-187)
  *   dist_out  the fp32 distance the reference search returns with it

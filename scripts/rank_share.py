@@ -2,10 +2,10 @@
 the cloud to move (the synthetic cloud's rows are in random order, so that is a random eighth)
 against the whole 64M-point tree, at the initial pose and at the converged pose (taken from a
 registration of the whole cloud, as the ranks' all-reduced sums would give it), next to the pass
-over the whole cloud.  icp_hip_nn is timed (it also writes rows and distances, ~20 % more than
-the pass inside the loop).  With a third argument "spatial" the eighth is a spatially compact one
-instead (median splits of the cloud to move along x, y, z: what a caller that partitions a scan by
-position hands to a rank).  usage: python scripts/rank_share.py [n] [share] [rows|spatial]"""
+over the whole cloud.  icp_hip_nn is timed, on freshly uploaded shards: their order is the one
+computed around the SHARD's mean, which misfits a spatially compact shard (third argument
+"spatial": median splits along x, y, z) -- scripts/rank_replay.py replays a rank inside the loop,
+where such a shard is ordered again.  usage: python scripts/rank_share.py [n] [share] [rows|spatial]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.getcwd())

@@ -135,3 +135,26 @@ def test_bench_launcher_reports_a_failing_rank():
     if r.returncode == 0:
         pytest.skip("a GPU node with >= 2 devices: the real launch ran")
     assert "exited with status" in r.stderr or "needs GPU" in r.stderr
+
+
+def test_spatial_shard_partition():
+    """icp_amd.dist.spatial_shard: the parts of all ranks are disjoint, cover the cloud, differ in
+    size by at most one point per cut, and are compact (a part's bounding box holds about its
+    share of the cloud's volume, where a random subset's box is the whole cloud)."""
+    from icp_amd import synth
+    from icp_amd.dist import spatial_shard
+    for n, world in ((10_000, 1), (10_001, 2), (9_999, 3), (40_000, 8), (5, 8), (0, 4)):
+        xyz = synth.cloud(n, seed=5) if n else np.zeros((0, 3), np.float32)
+        parts = [spatial_shard(xyz, world, r) for r in range(world)]
+        allrows = np.concatenate(parts)
+        assert len(allrows) == n and (np.sort(allrows) == np.arange(n)).all()
+        sizes = [len(q) for q in parts]
+        assert max(sizes) - min(sizes) <= 3
+        assert all((np.diff(q) > 0).all() for q in parts)
+        if n >= 10_000 and world > 1:
+            vol = np.prod(xyz.max(0) - xyz.min(0))
+            for q in parts:
+                box = np.prod(xyz[q].max(0) - xyz[q].min(0))
+                assert box < 1.6 * vol / world
+    with pytest.raises(ValueError):
+        spatial_shard(np.zeros((4, 3), np.float32), 2, 2)

@@ -146,3 +146,81 @@ def test_host_and_device_loops_agree_across_the_pass_on_a_large_shard(monkeypatc
     assert (bits(res[0][0]) == bits(res[1][0])).all()
     assert (bits(res[0][3]) == bits(res[1][3])).all()
     assert np.abs(res[0][0].astype(np.float64) - synth.expected_transform(0.5)).max() < 1e-5
+
+
+def _replay(ctx, capi, shard, n_total, mu_m, iters, rec):
+    """Register `shard` alone with the recorded all-reduced sums of the whole cloud's run in place
+    of its own: what it would see as one rank of many."""
+    k = [0]
+
+    def cb(a):
+        a[:] = rec[k[0]]
+        k[0] += 1
+    ctx.set_allreduce(cb)
+    ctx.set_queries(shard, n_total=n_total)
+    T, it, err = ctx.run(mu_m, iters, 0.0)
+    return T, it, ctx.get_points(), np.array(ctx.nn_trace())
+
+
+def test_compact_shard_is_ordered_again_around_the_clouds_mean(monkeypatch, capfd):
+    """A shard's set-up order is the leaf order of p - mean(shard); the loop searches
+    p - mean(whole cloud), known after the first all-reduce (icp_hip.cc, recentre_order).  A
+    spatially compact shard is ordered again around that mean, a random one is not; either way the
+    rank sees the sums of the whole run, ends with its transform bit for bit and returns its part
+    of the moved cloud in its own row order."""
+    from icp_amd import capi, synth
+    from icp_amd.dist import spatial_shard
+    n, iters = 1_000_000, 6
+    m = synth.cloud(n, seed=31)
+    mu_m = capi.mean_host(m)
+    mc = capi.center_host(m, mu_m)
+    p = synth.apply_fp32(m, synth.ground_truth(0.5))
+    rec = []
+    with capi.Context() as ctx:
+        ctx.build_tree(mc, 256)
+        ctx.set_allreduce(lambda a: rec.append(a.copy()))
+        ctx.set_queries(p)
+        T0, it0, _ = ctx.run(mu_m, iters, 0.0)
+        whole = ctx.get_points()
+        capfd.readouterr()
+        for rows, expect in ((spatial_shard(m, 2, 1), "shard ordered again"),
+                             (np.arange(n // 2), "order kept")):
+            res = {}
+            for mode in ("0", "v"):
+                monkeypatch.setenv("ICP_HIP_RECENTRE", mode)
+                res[mode] = _replay(ctx, capi, np.ascontiguousarray(p[rows]), n, mu_m, iters, rec)
+                said = capfd.readouterr().err
+                assert ("[recentre]" in said) == (mode == "v")
+                if mode == "v":
+                    assert expect in said
+            for T, it, moved, _ in res.values():
+                assert it == it0 and (bits(T) == bits(T0)).all()
+                assert (bits(moved) == bits(whole[rows])).all()
+
+
+def test_recentred_order_under_a_communicator(monkeypatch, capfd):
+    """The same step in the device-resident loop of a communicator run.  One rank is all this box
+    can start, so the shard is declared part of a larger cloud (n_total > n_local): the mean the
+    loop forms from the all-reduced sums is then far from the shard's own, the shard is ordered
+    again before the first pass, and the run equals the one without that step up to the order of
+    the fp64 sums."""
+    from icp_amd import capi, synth
+    n = 600_000
+    m = synth.cloud(n, seed=33)
+    mu_m = capi.mean_host(m)
+    mc = capi.center_host(m, mu_m)
+    p = synth.apply_fp32(m, synth.ground_truth(0.5))[: n // 2]
+    res = {}
+    for mode in ("0", "v"):
+        monkeypatch.setenv("ICP_HIP_RECENTRE", mode)
+        with capi.Context() as ctx:
+            ctx.build_tree(mc, 256)
+            ctx.comm_init_rank(1, 0, capi.Context.comm_unique_id())
+            ctx.set_queries(p, n_total=n)
+            capfd.readouterr()
+            T, it, err = ctx.run(mu_m, 3, 0.0)
+            assert ("shard ordered again" in capfd.readouterr().err) == (mode == "v")
+            res[mode] = (T.copy(), it, ctx.get_points())
+    assert res["0"][1] == res["v"][1] == 3
+    assert np.abs(res["0"][0] - res["v"][0]).max() <= 1e-5
+    assert np.abs(res["0"][2] - res["v"][2]).max() <= 1e-5
