@@ -89,6 +89,23 @@ def main():
             new_p = ctx.get_points()
         result.update(T=[float(v) for v in T.reshape(-1)], iters=int(iters), err=float(err),
                       new_p=new_p.tolist())
+    elif mode == "gpu_spatial":
+        # spatially compact shards (icp_amd.dist.spatial_shard) of a cloud large enough for the
+        # library to order each shard again around the whole cloud's mean (recentre_order)
+        from icp_amd.dist import spatial_shard
+        n2 = 400_000
+        m2 = synth.cloud(n2, seed=23)
+        p2 = synth.apply_fp32(m2, synth.ground_truth(1.0))
+        rows = spatial_shard(p2, world, rank)
+        mu_m = capi.mean_host(m2)
+        with capi.Context(0) as ctx:
+            ctx.build_tree(capi.center_host(m2, mu_m), 256)
+            ctx.set_queries(np.ascontiguousarray(p2[rows]), n_total=n2)
+            ctx.set_allreduce(allreduce)
+            T, iters, err = ctx.run(mu_m, 30, 1e-5)
+            new_p = ctx.get_points()
+        np.savez(f"{out_path}.{rank}.npz", rows=rows, new_p=new_p)
+        result.update(T=[float(v) for v in T.reshape(-1)], iters=int(iters), err=float(err))
     else:
         # real GPU, both ranks on device 0, sums exchanged over gloo through the C-ABI callback
         mu_m = capi.mean_host(m)

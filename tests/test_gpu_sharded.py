@@ -26,6 +26,29 @@ def test_two_contexts_match_one(tmp_path):
     assert new_p.shape == new_p1.shape and np.abs(new_p - new_p1).max() <= 1e-6
 
 
+def test_spatially_compact_shards_match_one_context(tmp_path):
+    """The partition bench.py --gpus N uses (icp_amd.dist.spatial_shard): each rank registers its
+    compact part, which the library orders again around the whole cloud's mean; the parts put
+    back with out[rows] = new_p are the single-context result."""
+    import icp_amd
+    from icp_amd import synth
+    n = 400_000
+    m = synth.cloud(n, seed=23)
+    p = synth.apply_fp32(m, synth.ground_truth(1.0))
+    T1, new_p1, info = icp_amd.icp(m, p, 30, 1e-5, 256, return_info=True)
+    res = run_workers("gpu_spatial", str(tmp_path / "out"))
+    out = np.full_like(new_p1, np.nan)
+    seen = 0
+    for r in res:
+        assert r["iters"] == info["iterations"]
+        assert np.abs(np.array(r["T"], np.float32).reshape(4, 4) - T1).max() <= 1e-6
+        z = np.load(str(tmp_path / "out") + f".{r['rank']}.npz")
+        out[z["rows"]] = z["new_p"]
+        seen += len(z["rows"])
+    assert seen == n and res[0]["T"] == res[1]["T"]
+    assert np.abs(out - new_p1).max() <= 1e-6
+
+
 def test_empty_shard_takes_part_in_every_collective(tmp_path):
     """More ranks than points: a rank with an empty shard issues the same all-reduces and ends
     with the same transform."""
