@@ -818,12 +818,14 @@ namespace
                          c->q_extent > 0.0;
         if (sharded ? c->resort_decided : (c->resorted || !can))
             return ICP_HIP_OK;
-        if (c->allreduce || st.done || st.started == 0 || st.max_iters - st.started < 4u ||
+        if (st.done || st.started == 0 || st.max_iters - st.started < 4u ||
             !at_block_end(c, st.started))
             return ICP_HIP_OK;
-        // the scale the motion is compared with: the shard's own extent, or with a communicator
-        // the diameter of the tree's root sphere (a median distance: about the cloud's extent)
-        const double extent = sharded ? 2.0 * (double)c->root_radius : c->q_extent;
+        // the scale the motion is compared with: the cloud's extent -- the shard's own when the
+        // shard is the cloud, else the diameter of the tree's root sphere (a median distance:
+        // about the extent of the reference cloud, the same on every rank)
+        const double extent =
+            sharded || c->n_total > c->n_local ? 2.0 * (double)c->root_radius : c->q_extent;
         if (!(extent > 0.0))
             return ICP_HIP_OK;
         // the last iteration moved x to R x + t: by at most |R - I|_F |x - mu_m| + |R mu_m + t - mu_m|
@@ -853,6 +855,9 @@ namespace
         if (!can || c->resorted)
             return ICP_HIP_OK;
         c->resorted = true;
+        if (const char* env = std::getenv("ICP_HIP_RESORT"))
+            if (env[0] == 'v')
+                std::fprintf(stderr, "[resort] second ordering pass after iteration %u\n", st.started);
         // From here on the clouds are aligned: larger chunks cost the aligned pass nothing (it
         // no longer depends on two batches of a bucket meeting in L2: 2.42 -> 2.34 ms at 64M
         // points with 8 batches per chunk) -- the misaligned passes before did need the small
@@ -1419,6 +1424,10 @@ namespace
             {
                 HIP_TRY(c, hipStreamSynchronize(c->stream));
                 ap_ms = n ? elapsed_ms(c) : 0.f;
+                // (after the apply pass, which still needed this iteration's matches; every rank
+                // decides about its own shard from the all-reduced state, as under RCCL)
+                if ((rc = maybe_resort(c, st)) != ICP_HIP_OK)
+                    return rc;
             }
         }
         loop_results(c, st, T_out, iters_done, final_error);

@@ -2,8 +2,7 @@
 the all-reduce callback records the all-reduced sums of every slot; the shard is then registered
 alone, with a callback that puts the recorded sums in place of its own: it sees exactly what it
 would see as one of N ranks (the same centroids and transforms), and its NN passes are a rank's.
-(Host-driven loop, as always with a callback: no second ordering pass, so the late iterations are
-those of the set-up order.)  usage: python scripts/rank_replay.py [n] [share] [rows|spatial] [iters]"""
+(Host-driven loop, as always with a callback.)  usage: python scripts/rank_replay.py [n] [share] [rows|spatial] [iters]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.getcwd())

@@ -167,10 +167,11 @@ def test_compact_shard_is_ordered_again_around_the_clouds_mean(monkeypatch, capf
     p - mean(whole cloud), known after the first all-reduce (icp_hip.cc, recentre_order).  A
     spatially compact shard is ordered again around that mean, a random one is not; either way the
     rank sees the sums of the whole run, ends with its transform bit for bit and returns its part
-    of the moved cloud in its own row order."""
+    of the moved cloud in its own row order -- across the second ordering pass as well."""
     from icp_amd import capi, synth
     from icp_amd.dist import spatial_shard
-    n, iters = 1_000_000, 6
+    n, iters = 1_200_000, 12
+    monkeypatch.setenv("ICP_HIP_RESORT", "v")
     m = synth.cloud(n, seed=31)
     mu_m = capi.mean_host(m)
     mc = capi.center_host(m, mu_m)
@@ -193,6 +194,9 @@ def test_compact_shard_is_ordered_again_around_the_clouds_mean(monkeypatch, capf
                 assert ("[recentre]" in said) == (mode == "v")
                 if mode == "v":
                     assert expect in said
+                # long enough, and the shard large enough, for the second ordering pass: a
+                # callback-driven run takes it too, each rank for its own shard
+                assert "second ordering pass" in said
             for T, it, moved, _ in res.values():
                 assert it == it0 and (bits(T) == bits(T0)).all()
                 assert (bits(moved) == bits(whole[rows])).all()
