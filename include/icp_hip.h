@@ -159,9 +159,14 @@ int icp_hip_get_tree(icp_hip_ctx* ctx, icp_flat_tree** out);
  * of *out is set to NULL.  Nothing is copied from the device. */
 int icp_hip_get_tree_info(icp_hip_ctx* ctx, icp_flat_tree* out);
 
-/* Upload this context's contiguous shard of the cloud to move ("p", icp.hh:20).
+/* Upload this context's shard of the cloud to move ("p", icp.hh:20).
  * Replaces GPUMatrix::from_point_list (libgpu/libgpu/matrix.cu:95-103).
- * n_total is the size of the whole cloud over all shards (== n_local on one GPU). */
+ * n_total is the size of the whole cloud over all shards (== n_local on one GPU).  Any partition
+ * of the cloud's rows over the ranks gives the same registration; a rank searches the whole tree
+ * for its shard, so spatially compact shards cost it about its share of the one-GPU pass and
+ * random subsets 1.5-1.75x that.  The library stores the shard in an order
+ * of its own (and, in a sharded run, orders it again once the whole cloud's mean is known);
+ * rows, distances and the moved cloud always come back in the order given here. */
 int icp_hip_set_queries(icp_hip_ctx* ctx, const float* xyz_aos, uint64_t n_local,
                         uint64_t n_total);
 
