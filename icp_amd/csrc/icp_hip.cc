@@ -275,6 +275,8 @@ struct icp_hip_ctx
     float root_radius = 0.f;     // radius of the tree's root sphere (the same tree on every rank)
     double q_extent = 0.0; // largest side of the shard's bounding box at set-up
     float order_mu[3] = {0.f, 0.f, 0.f}; // the centre the shard's leaf order was computed around
+    float mean_hint[3] = {0.f, 0.f, 0.f}; // the whole cloud's mean as the last sharded run saw it
+    uint64_t mean_hint_n_total = 0;       // ... for a cloud of this many points (0: none)
     DevBuf<uint32_t> sk_keys, sk_keys2, sk_idx, sk_order; // the sorts' arrays, kept for maybe_resort
     DevBuf<unsigned char> sk_temp;
     // small shard (kSmallBelow): px/py/pz, queue and loop_state are views into `qblock`
@@ -625,7 +627,7 @@ namespace
     // Store the shard in Morton order of its positions (sort.hip), then in leaf order; c->aos
     // holds the input AoS.  The key / index / temporary arrays stay with the context: a long
     // registration orders the shard a second time once the clouds are aligned (maybe_resort).
-    int sort_queries(icp_hip_ctx* c, uint32_t n)
+    int sort_queries(icp_hip_ctx* c, uint32_t n, uint64_t n_total)
     {
         const uint32_t grid = stream_grid(n);
         DevBuf<float> mm;
@@ -700,8 +702,14 @@ namespace
             HIP_TRY(c, hipMemcpyAsync(c->h_sums, c->sums.p, sizeof(double) * kApplySums,
                                       hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
-            const float mu[3] = {(float)(c->h_sums[1] / n), (float)(c->h_sums[2] / n),
-                                 (float)(c->h_sums[3] / n)};
+            float mu[3] = {(float)(c->h_sums[1] / n), (float)(c->h_sums[2] / n),
+                           (float)(c->h_sums[3] / n)};
+            // a shard of a larger cloud: the loop will search around the whole cloud's mean,
+            // which this context has seen if it registered a shard of a cloud of this size
+            // before (recentre_order).  Only a hint: any centre gives the same answers, and a
+            // stale one is corrected after the run's first all-reduce.
+            if (n_total > n && c->mean_hint_n_total == n_total)
+                std::memcpy(mu, c->mean_hint, sizeof mu);
             int rc = leaf_order_pass(c, n, mu);
             if (rc != ICP_HIP_OK)
                 return rc;
@@ -735,6 +743,8 @@ namespace
             const double d = (double)mu[k] - (double)c->order_mu[k];
             d2 += d * d;
         }
+        std::memcpy(c->mean_hint, mu, sizeof mu); // for the next shard of a cloud of this size
+        c->mean_hint_n_total = c->n_total;
         const double spacing = 2.0 * (double)c->root_radius / std::cbrt((double)c->n_tree_points);
         const bool again = std::sqrt(d2) > 0.25 * spacing;
         if (env && env[0] == 'v') // verbose: what the decision was taken from
@@ -2029,7 +2039,7 @@ extern "C"
                             std::string("icp_hip_set_queries: ") + icp_host::kNonFiniteMessage);
             if (want_sort)
             {
-                int rc = sort_queries(c, (uint32_t)n_local);
+                int rc = sort_queries(c, (uint32_t)n_local, n_total);
                 if (rc != ICP_HIP_OK)
                     return rc;
             }

@@ -200,6 +200,12 @@ def test_compact_shard_is_ordered_again_around_the_clouds_mean(monkeypatch, capf
             for T, it, moved, _ in res.values():
                 assert it == it0 and (bits(T) == bits(T0)).all()
                 assert (bits(moved) == bits(whole[rows])).all()
+        # the context remembers the whole cloud's mean: the next shard of a cloud of this size is
+        # ordered around it at set-up, and the run finds nothing to order again
+        rows = spatial_shard(m, 2, 1)
+        T, it, moved, _ = _replay(ctx, capi, np.ascontiguousarray(p[rows]), n, mu_m, iters, rec)
+        assert "order kept" in capfd.readouterr().err
+        assert it == it0 and (bits(T) == bits(T0)).all() and (bits(moved) == bits(whole[rows])).all()
 
 
 def test_recentred_order_under_a_communicator(monkeypatch, capfd):
