@@ -251,7 +251,7 @@ namespace icp_dev
                     const bool take_up = gu <= gd;
                     const float gap = take_up ? gu : gd;
                     const float ref = take_up ? ru : rl;
-                    const float g = __fsub_rn(gap, __fadd_rn(__fmul_rn(__fadd_rn(ref, dq), 0x1p-20f), 1e-18f));
+                    const float g = __fsub_rn(gap, __fmaf_rn(__fadd_rn(ref, dq), 0x1p-20f, 1e-18f));
                     if (g > 0.f && __fmul_rn(g, g) > __fmul_rn(m1, 1.00001f))
                         done = true; // (both sides exhausted: the gap is +inf)
                     else if (it < kWalkMax)
@@ -698,7 +698,7 @@ namespace icp_dev
                             const float da = __builtin_amdgcn_sqrtf(d2); // as in the general step
                             const float lb = __fsub_rn(
                                 fminf(fabsf(__fsub_rn(N.r, da)), da),
-                                __fadd_rn(__fmul_rn(__fadd_rn(da, N.r), 0x1p-20f), 1e-18f));
+                                __fmaf_rn(__fadd_rn(da, N.r), 0x1p-20f, 1e-18f));
                             chain_track(chain_m, chain_m2, arg, lb, node);
                             const int go = d2 < N.thr ? N.inside : N.outside; // :147-148
                             if (go >= 0)
@@ -756,7 +756,7 @@ namespace icp_dev
                                 const float da = __builtin_amdgcn_sqrtf(d2);
                                 const float lb = __fsub_rn(
                                     fminf(fabsf(__fsub_rn(N.r, da)), da),
-                                    __fadd_rn(__fmul_rn(__fadd_rn(da, N.r), 0x1p-20f), 1e-18f));
+                                    __fmaf_rn(__fadd_rn(da, N.r), 0x1p-20f, 1e-18f));
                                 chain_track(chain_m, chain_m2, arg, lb, node);
                             }
                             const int nearc = in_near ? N.inside : N.outside;
