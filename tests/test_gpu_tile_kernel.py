@@ -219,3 +219,28 @@ def test_ring_walk_with_many_queries_per_bucket(oracle, noise):
     assert (bits(got["dist"][sub]) == bits(want["dist"])).all()
     assert (bits(got["xyz"][sub]) == bits(want["xyz"])).all()
     tree.close()
+
+
+def test_outputs_not_asked_for_are_not_needed():
+    """icp_hip_nn computes rows and distances on the device only when the caller passes a buffer
+    for them (they go back to the caller's order with scattered stores): every subset of the
+    outputs gives the same values as the full call."""
+    from icp_amd import capi, synth
+    n = 300_000
+    m = synth.cloud(n, seed=41)
+    mu_m = capi.mean_host(m)
+    p = synth.apply_fp32(m, synth.ground_truth(0.5))[np.random.default_rng(2).permutation(n)]
+    mu_p = capi.mean_host(p)
+    with capi.Context() as ctx:
+        ctx.build_tree(capi.center_host(m, mu_m), 256)
+        ctx.set_queries(p)
+        full = ctx.nn(mu_p)
+        for want in (("xyz",), ("row",), ("dist",), ("row", "dist"), ()):
+            part = ctx.nn(mu_p, want=want)
+            for k in ("row", "xyz", "dist"):
+                if k in want:
+                    assert (bits(part[k]) == bits(full[k])).all() if k != "row" else (part[k] == full[k]).all()
+                else:
+                    assert part[k] is None
+        again = ctx.nn(mu_p)
+        assert (again["row"] == full["row"]).all() and (bits(again["dist"]) == bits(full["dist"])).all()
