@@ -154,11 +154,20 @@ def main():
     import numpy as np
     import torch  # device plumbing + torch.distributed only
     import torch.distributed as dist
+    # ICP_BENCH_SHARE_GPU=1: every rank on GPU 0, sums exchanged over gloo through the host
+    # callback -- the whole N-rank flow (partition, shards of a larger cloud, one all-reduce per
+    # iteration) on a box with ONE GPU, where RCCL refuses a second rank.  Not a measurement: the
+    # line says so in config.allreduce.
+    share_gpu = world > 1 and os.environ.get("ICP_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     if local_rank >= torch.cuda.device_count():
         raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank}, but this node has "
                          f"{torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if share_gpu:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    elif world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from icp_amd import capi, synth
@@ -220,7 +229,11 @@ def main():
     # together to the host-callback all-reduce through torch.distributed (the path the 2-rank
     # tests cover), and the line says so.
     allreduce_path = "none (one rank)"
-    if world > 1:
+    if share_gpu:
+        from icp_amd.dist import torch_allreduce
+        ctx.set_allreduce(torch_allreduce())
+        allreduce_path = "REHEARSAL on one shared GPU: gloo all-reduce from the host loop"
+    elif world > 1:
         allreduce_path = "rccl communicator on the context's stream"
         try:
             init_rccl(ctx, world, rank)
@@ -272,7 +285,7 @@ def main():
     barrier_sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     assert iters == args.steps

@@ -132,3 +132,30 @@ def test_rccl_communicator_single_rank():
             if cap_iters:
                 assert np.abs(res[0][4].mean(0, dtype=np.float64) - mu_m).max() <= 3e-7
     tree.close()
+
+
+def test_bench_flow_with_two_ranks_sharing_the_gpu():
+    """bench.py --gpus 2 end to end on the one GPU of the box (ICP_BENCH_SHARE_GPU=1: both ranks on
+    GPU 0, gloo all-reduce through the host callback, because RCCL refuses a second rank on a
+    device): it starts its ranks, hands them compact shards of the larger cloud, registers and
+    prints one line for the job."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, ICP_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "custom",
+                        "--points", "400000", "--steps", "8", "--warmup", "1", "--cpu-sample", "0"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 8 and j["scaling"] == "strong"
+    assert j["config"]["queries_total"] == 400000 and j["config"]["queries_per_gpu"] == 200000
+    assert "spatial_shard" in j["config"]["shards"] and "REHEARSAL" in j["config"]["allreduce"]
+    assert j["check"]["max_abs_T_minus_expected"] < 2e-5
+    assert abs(j["value"] - 400000 * 8 / (j["ms_per_step"] * 8e-3)) < 1e-3 * j["value"]
