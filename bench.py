@@ -57,6 +57,9 @@ def parse(argv=None):
                     help="queries of the CPU-baseline sample (0 disables the baseline)")
     ap.add_argument("--cpu-repeats", type=int, default=0,
                     help="CPU-baseline repeats (default: 5 at <= 4M points, 3 above; median taken)")
+    ap.add_argument("--allow-fallback", action="store_true",
+                    help="N > 1: if the RCCL communicator does not come up on every rank, let all "
+                         "ranks fall back to the host-callback all-reduce instead of exiting non-zero")
     ap.add_argument("--rehearse", action="store_true",
                     help="launcher rehearsal without a GPU: start the ranks, rendezvous over gloo, "
                          "split the shards, print the line's launch fields and exit")
@@ -110,6 +113,28 @@ def cpu_model() -> str:
 def median(v):
     v = sorted(v)
     return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
+
+
+def load_counters(args, n_m, n_queries_total):
+    """profiles/nn_counters_<workload>.json if it belongs to THIS command, else None.  The file
+    holds the per-launch means of the builder's rocprofv3 --pmc passes; its key is workload, timed
+    steps, capacity, angle, query count, one GPU.  The warm-up count is not part of the key:
+    set_queries puts the shard back to the initial clouds after the warm-up, so the timed
+    launches are the same whatever W was."""
+    path = os.path.join(ROOT, "profiles", f"nn_counters_{args.workload}.json")
+    try:
+        with open(path) as f:
+            cj = json.load(f)
+        if cj.get("workload") == args.workload and cj.get("n_gpus", 1) == 1 and \
+                cj.get("steps") == args.steps and \
+                int(cj.get("capacity", 256)) == args.capacity and \
+                abs(float(cj.get("angle", 0.25 if n_m > 8_000_000 else 1.0)) - args.angle) < 1e-12 and \
+                int(cj.get("queries", n_m)) == n_queries_total and \
+                float(cj["valu_insts_per_launch"]) > 0 and float(cj["hbm_bytes_per_launch"]) > 0:
+            return cj
+    except Exception:
+        pass
+    return None
 
 
 def rehearse(args, rank, world):
@@ -225,30 +250,49 @@ def main():
     ctx = capi.Context(local_rank)
     # The per-iteration all-reduce: the context's own RCCL communicator, enqueued on its stream
     # between the kernels (xGMI).  More than one RCCL rank has never run where this was built
-    # (one GPU per box): if the communicator does not come up on EVERY rank, all ranks fall back
-    # together to the host-callback all-reduce through torch.distributed (the path the 2-rank
-    # tests cover), and the line says so.
+    # (one GPU per box).  If the communicator does not come up on EVERY rank the job exits
+    # non-zero: a line measured on the other loop must not pass for the RCCL one.  With
+    # --allow-fallback all ranks switch together to the host-callback all-reduce through
+    # torch.distributed (the path the 2-rank tests cover), and the line says so.
     allreduce_path = "none (one rank)"
-    if share_gpu:
-        from icp_amd.dist import torch_allreduce
-        ctx.set_allreduce(torch_allreduce())
-        allreduce_path = "REHEARSAL on one shared GPU: gloo all-reduce from the host loop"
-    elif world > 1:
+    # ICP_BENCH_TEST_COMM_FAILURE=<rank>: that rank pretends its communicator failed (tests of
+    # the decision below on a one-GPU box, together with ICP_BENCH_SHARE_GPU=1)
+    simulate = os.environ.get("ICP_BENCH_TEST_COMM_FAILURE")
+    if world > 1 and (not share_gpu or simulate is not None):
         allreduce_path = "rccl communicator on the context's stream"
         try:
-            init_rccl(ctx, world, rank)
+            if simulate is not None and int(simulate) == rank:
+                raise RuntimeError("simulated communicator failure (ICP_BENCH_TEST_COMM_FAILURE)")
+            if not share_gpu:
+                init_rccl(ctx, world, rank)
             ok = 1.0
         except Exception as e:  # capi.IcpHipError, or the rendezvous
             print(f"[bench rank {rank}] RCCL communicator failed: {e}", file=sys.stderr, flush=True)
             ok = 0.0
-        flag = torch.tensor([ok], dtype=torch.float64, device="cuda")
+        flag = torch.tensor([ok], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if flag.item() < 1.0 and not args.allow_fallback:
+            ctx.close()
+            dist.destroy_process_group()
+            raise SystemExit(f"bench.py: rank {rank}: the RCCL communicator did not come up on "
+                             f"every rank (see the messages above); --allow-fallback runs the "
+                             f"host-callback all-reduce instead")
         if flag.item() < 1.0:
             from icp_amd.dist import torch_allreduce
             ctx.close()
             ctx = capi.Context(local_rank)
-            ctx.set_allreduce(torch_allreduce(device=torch.device("cuda", local_rank)))
+            ctx.set_allreduce(torch_allreduce(
+                device=None if share_gpu else torch.device("cuda", local_rank)))
             allreduce_path = "FALLBACK: torch.distributed all-reduce from the host loop"
+            share_gpu_cb = False
+        else:
+            share_gpu_cb = share_gpu
+    else:
+        share_gpu_cb = share_gpu
+    if share_gpu_cb:
+        from icp_amd.dist import torch_allreduce
+        ctx.set_allreduce(torch_allreduce())
+        allreduce_path = "REHEARSAL on one shared GPU: gloo all-reduce from the host loop"
     ctx.build_tree(mc[:4096], args.capacity)   # first-call costs (code load) out of the timing
     t0 = time.time()
     ctx.build_tree(mc, args.capacity)
@@ -284,6 +328,7 @@ def main():
     T, iters, err = ctx.run(mu_m, args.steps, 0.0)
     barrier_sync()
     dt = time.perf_counter() - t0
+    my_dt = dt
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -312,21 +357,14 @@ def main():
     # scanned) is kept as `algorithmic_GBs`: it charges every query for bucket bytes that ~50
     # queries share, so it exceeds the HBM peak and is not a fraction of anything.
     launches = max(1, int(tm["nn_launches"]))
+    # the loop's work counters ride on the all-reduce: they are the JOB's totals on every rank
     alg_bytes_all = 16.0 * tm["queries"] + 16.0 * tm["nodes_visited"] + 12.0 * tm["points_scanned"]
-    bytes_per_launch = alg_bytes_all / launches / world       # one GPU's launch
+    bytes_per_launch = alg_bytes_all / launches / world       # one GPU's launch (mean over ranks)
     avg_ms = tm["nn_ms"] / launches
     avg_s = avg_ms * 1e-3
-    counters, cpath = None, os.path.join("profiles", f"nn_counters_{args.workload}.json")
-    if os.path.exists(os.path.join(ROOT, cpath)):
-        try:
-            with open(os.path.join(ROOT, cpath)) as f:
-                cj = json.load(f)
-            if cj.get("workload") == args.workload and cj.get("n_gpus", 1) == world == 1 and \
-                    cj.get("steps") == args.steps and cj.get("warmup") == args.warmup:
-                counters = cj
-        except Exception:
-            counters = None
     n_gpu = float(end - begin)
+    cpath = os.path.join("profiles", f"nn_counters_{args.workload}.json")
+    counters = load_counters(args, n_m, n_queries_total)
     tree_bytes = 12.0 * tinfo["n_slots"] + 32.0 * tinfo["n_nodes"]
     compulsory = 16.0 * n_gpu + min(tree_bytes, bytes_per_launch)
     flops_per_launch = 8.0 * (tm["points_scanned"] + tm["nodes_visited"]) / launches / world
@@ -334,13 +372,15 @@ def main():
     flop_ach = flops_per_launch / avg_s / 1e12
     issue_peak = SIMDS * CLOCK_HZ / VALU_ISSUE_CYCLES / 1e9   # G wave-instructions / s
     roofline = {"kernel": "nn_tile_kernel", "avg_launch_ms": round(avg_ms, 4), "launches": launches,
+                "bound": "valu_issue", "achieved": None, "peak": round(issue_peak, 1),
+                "unit": "G wave-instr/s", "frac": None,
                 "traffic": None, "hbm": None, "counters_from": None,
-                "fp32_no_fma": {"achieved": round(flop_ach, 2), "peak": round(flop_peak, 2),
-                                "unit": "TFLOP/s", "frac": round(flop_ach / flop_peak, 4),
-                                "note": "8 flops per distance in the reference's arithmetic "
-                                        "(3 sub, 3 mul, 2 add, never contracted); the scan's "
-                                        "filter spends 6 operations with FMA and re-checks the "
-                                        "winner with the reference's"},
+                "reference_arithmetic": {
+                    "TFLOP/s": round(flop_ach, 2), "fp32_no_fma_peak": round(flop_peak, 2),
+                    "note": "8 flops per distance of the REFERENCE traversal (points_scanned and "
+                            "nodes_visited count what libcpu scans; the ring walk examines 1-2 of "
+                            "a bucket's points once the clouds are aligned): a work rate, not a "
+                            "utilisation of this kernel"},
                 "algorithmic_GBs": round(bytes_per_launch / avg_s / 1e9, 1),
                 "algorithmic_bytes_per_launch": round(bytes_per_launch),
                 "bytes_per_query": round(alg_bytes_all / max(1.0, tm["queries"]), 1),
@@ -348,25 +388,59 @@ def main():
                 "stack_spills": tm.get("stack_spills", 0.0),
                 "measured_copy_GBs": round(copy_gbs, 1) if copy_gbs else None}
     if counters:
-        valu = float(counters["valu_insts_per_launch"])
-        traffic = float(counters["hbm_bytes_per_launch"])
+        # N == 1: the file's per-launch means are this command's.  N > 1: rank 0 runs its shard of
+        # the same cloud against the same tree; instructions and bytes are taken PER QUERY from
+        # the one-GPU passes and multiplied by the shard's queries -- an estimate, labelled so
+        # (a compact shard costs 1.0-1.15x its share of the one-GPU pass).
+        share = n_gpu / float(counters.get("queries", n_m))
+        valu = float(counters["valu_insts_per_launch"]) * share
+        traffic = float(counters["hbm_bytes_per_launch"]) * share
         ach = valu / avg_s / 1e9
+        src = (f"{cpath}: rocprofv3 --pmc passes of this command by the builder "
+               f"({counters.get('tag', '?')}), not measured by this run")
+        if world > 1:
+            src += (f"; scaled by rank 0's share of the queries ({share:.4f}): an ESTIMATE for a "
+                    f"shard, the passes were taken on one GPU")
         roofline.update({
-            "bound": "valu_issue", "achieved": round(ach, 1), "peak": round(issue_peak, 1),
-            "unit": "G wave-instr/s", "frac": round(ach / issue_peak, 4),
+            "achieved": round(ach, 1), "frac": round(ach / issue_peak, 4),
             "traffic": round(traffic),
             "hbm": {"achieved": round(traffic / avg_s / 1e9, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4),
                     "frac_of_measured_copy": (round(traffic / avg_s / 1e9 / copy_gbs, 4)
                                               if copy_gbs else None),
                     "traffic_over_compulsory": round(traffic / compulsory, 2)},
-            "counters_from": f"{cpath}: rocprofv3 --pmc passes of this command by the builder "
-                             f"({counters.get('tag', '?')}), not measured by this run"})
+            "counters_from": src})
     else:
-        # no counter file for this command: fall back to the arithmetic the traversal must do
-        roofline.update({"bound": "valu_fp32_no_fma", "achieved": round(flop_ach, 2),
-                         "peak": round(flop_peak, 2), "unit": "TFLOP/s",
-                         "frac": round(flop_ach / flop_peak, 4)})
+        # no counter file for this command: no utilisation figure is invented for it
+        roofline["note"] = (f"no committed counter passes match this command ({cpath}: workload, "
+                            f"steps, capacity, angle, queries): frac / traffic are null")
+
+    # ---------------- per-rank record (N > 1: gathered after the timed region) ----------------
+    mine = {"rank": rank, "queries": int(end - begin), "wall_ms_per_step": round(my_dt / args.steps * 1e3, 4),
+            "nn_ms_per_step": round(tm["nn_ms"] / launches, 4),
+            "apply_ms_per_step": round(tm["apply_ms"] / launches, 4),
+            "nn_ms_first_iter": round(float(trace[0]), 4) if len(trace) else None,
+            "nn_ms_last_iter": round(float(trace[-1]), 4) if len(trace) else None,
+            "setup_s": {"generate_and_partition": round(t_gen, 2), "tree_build": round(t_build, 3)}}
+    per_rank, allreduce_probe = [mine], None
+    if world > 1:
+        # what ONE all-reduce of the loop's 16 doubles costs through this process group (the
+        # library's own communicator runs the same collective on its stream): 50 in a row
+        probe_dev = "cpu" if share_gpu else "cuda"
+        buf = torch.zeros(16, dtype=torch.float64, device=probe_dev)
+        for _ in range(5):
+            dist.all_reduce(buf)
+        barrier_sync()
+        tp = time.perf_counter()
+        for _ in range(50):
+            dist.all_reduce(buf)
+        if probe_dev == "cuda":
+            torch.cuda.synchronize()
+        allreduce_probe = {"us_per_allreduce_16_doubles": round((time.perf_counter() - tp) / 50 * 1e6, 2),
+                           "through": "torch.distributed " + ("gloo (host)" if share_gpu else "nccl (RCCL)")}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        per_rank = gathered
 
     out = None
     if rank == 0:
@@ -401,6 +475,9 @@ def main():
             "check": {"max_abs_T_minus_expected": t_err, "final_error": float(err)},
             "roofline": roofline,
         }
+        if world > 1:
+            out["per_rank"] = per_rank
+            out["allreduce_probe"] = allreduce_probe
 
     # ---------------- CPU baseline beside it (rank 0, N == 1 only) ----------------
     # One libcpu iteration on a bounded sample of the shard against the same tree, on the box's

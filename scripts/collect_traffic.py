@@ -8,7 +8,7 @@ collected and corrected as MI355X_MICROARCH.md (HBM section) prescribes:
   * WRITE_SIZE is taken as is.
 With --sq-csv (the SQ pass of the same command) the VALU wave-instructions per launch are added:
 the result is profiles/nn_counters_<workload>.json, which bench.py reads for its roofline block
-when workload, steps and warm-up match the command it is running.
+when workload, steps, capacity, angle and query count match the command it is running.
 Usage: collect_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> \
            [--sq-csv <sq_counter_collection.csv>] --points N --workload 64M --steps 20 --warmup 3 \
            --tag r02a --out profiles/nn_counters_64M.json
@@ -27,6 +27,8 @@ ap.add_argument("--steps", type=int, default=0, help="average over the last K la
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--sq-csv", default=None, help="pass with SQ_INSTS_VALU (and friends) of the same command")
 ap.add_argument("--tag", default="?")
+ap.add_argument("--capacity", type=int, default=256)
+ap.add_argument("--angle", type=float, default=None, help="default: bench.py's (0.25 above 8M points, else 1.0)")
 a = ap.parse_args()
 
 
@@ -47,7 +49,11 @@ write = w[nn]
 if a.steps:
     fetch, write = fetch[-a.steps:], write[-a.steps:]
 res = {
-    "workload": a.workload, "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "tag": a.tag,
+    # the key bench.py matches its command against (the warm-up count is NOT part of it: the shard
+    # is reset after the warm-up, the timed launches are the same)
+    "workload": a.workload, "n_gpus": 1, "steps": a.steps, "capacity": a.capacity,
+    "angle": a.angle if a.angle is not None else (0.25 if a.points > 8_000_000 else 1.0),
+    "queries": a.points, "warmup_of_the_profiled_run": a.warmup, "tag": a.tag,
     "kernel": nn,
     "fetch_size_calibration": {"kernel": cal, "known_bytes": 12 * a.points,
                                "reported_bytes": sum(f[cal]) / len(f[cal]), "factor": factor},

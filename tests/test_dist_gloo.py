@@ -158,3 +158,28 @@ def test_spatial_shard_partition():
                 assert box < 1.6 * vol / world
     with pytest.raises(ValueError):
         spatial_shard(np.zeros((4, 3), np.float32), 2, 2)
+
+
+def test_bench_counter_file_matches_the_driver_command():
+    """The driver runs `bench.py --gpus 1 --steps 20 --warmup 5`: the committed counter passes
+    (profiles/nn_counters_64M.json) must be accepted for it whatever the warm-up count, and
+    rejected for another command (steps, capacity, angle, query count)."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for warm in ("0", "3", "5", "11"):
+        a = bench.parse(["--gpus", "1", "--steps", "20", "--warmup", warm])
+        a.angle = 0.25
+        cj = bench.load_counters(a, 64_000_000, 64_000_000)
+        assert cj is not None and cj["valu_insts_per_launch"] > 0 and cj["hbm_bytes_per_launch"] > 0
+    for argv, nq in ((["--steps", "10"], 64_000_000), (["--capacity", "128"], 64_000_000),
+                     (["--steps", "20"], 8_000_000)):
+        a = bench.parse(argv)
+        a.angle = 0.25
+        assert bench.load_counters(a, 64_000_000, nq) is None
+    a = bench.parse(["--steps", "20"])
+    a.angle = 1.0
+    assert bench.load_counters(a, 64_000_000, 64_000_000) is None

@@ -159,3 +159,44 @@ def test_bench_flow_with_two_ranks_sharing_the_gpu():
     assert "spatial_shard" in j["config"]["shards"] and "REHEARSAL" in j["config"]["allreduce"]
     assert j["check"]["max_abs_T_minus_expected"] < 2e-5
     assert abs(j["value"] - 400000 * 8 / (j["ms_per_step"] * 8e-3)) < 1e-3 * j["value"]
+    # what makes a first N > 1 run diagnosable: one record per rank, a collective latency probe,
+    # and a roofline block that never carries a fraction it did not get from counters
+    assert [r["rank"] for r in j["per_rank"]] == [0, 1]
+    for r in j["per_rank"]:
+        assert r["queries"] == 200000 and r["nn_ms_per_step"] > 0 and r["apply_ms_per_step"] > 0
+        assert r["wall_ms_per_step"] <= j["ms_per_step"] * 1.001
+        assert r["nn_ms_first_iter"] > 0 and r["nn_ms_last_iter"] > 0
+    assert j["allreduce_probe"]["us_per_allreduce_16_doubles"] > 0
+    rf = j["roofline"]
+    assert rf["bound"] == "valu_issue" and rf["avg_launch_ms"] > 0
+    assert rf["frac"] is None and rf["traffic"] is None and "no committed counter passes" in rf["note"]
+
+
+def _bench_two_ranks(extra_env, extra_args=()):
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, ICP_BENCH_SHARE_GPU="1", **extra_env)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload",
+                           "custom", "--points", "100000", "--steps", "4", "--warmup", "1",
+                           "--cpu-sample", "0", *extra_args],
+                          env=env, cwd=ROOT, capture_output=True, text=True, timeout=280)
+
+
+def test_bench_exits_nonzero_when_a_communicator_fails():
+    """A rank whose RCCL communicator does not come up must fail the JOB (every rank, non-zero
+    status, no JSON line) unless --allow-fallback is given; with it the line names the fallback.
+    The failure is simulated on rank 1 (ICP_BENCH_TEST_COMM_FAILURE) on the shared GPU."""
+    import json
+    r = _bench_two_ranks({"ICP_BENCH_TEST_COMM_FAILURE": "1"})
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "did not come up on every rank" in r.stderr and "--allow-fallback" in r.stderr
+    r = _bench_two_ranks({"ICP_BENCH_TEST_COMM_FAILURE": "1"}, ("--allow-fallback",))
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert j["config"]["allreduce"].startswith("FALLBACK") and len(j["per_rank"]) == 2
+    assert j["check"]["max_abs_T_minus_expected"] < 5e-5
