@@ -1232,7 +1232,7 @@ namespace
         {
             // the same step on the host, into the image of the block: it goes up with the cloud
             LoopState* hs = reinterpret_cast<LoopState*>(c->h_up);
-            loop_init_step(hs, c->first_sums, mu_m, threshold, cap_iters, (double)c->n_total);
+            loop_init_step(hs, c->first_sums, mu_m, threshold, cap_iters, (double)c->n_total, false);
             if (c->upload_pending)
                 rc = flush_queries(c);
             else
@@ -1254,7 +1254,7 @@ namespace
                  (rc = recentre_order(c, c->h_sums + kApplyAt)) != ICP_HIP_OK))
                 return rc;
             HIP_TRY(c, launch_loop_init(c->loop_state, c->sums.p + kApplyAt, mu_m, threshold,
-                                        cap_iters, (double)c->n_total, c->stream));
+                                        cap_iters, (double)c->n_total, sharded, c->stream));
         }
         c->first_sums_valid = false; // the loop moves the cloud
         const uint32_t slots_cap = cap_iters == 0 ? 0u : cap_iters + (sharded ? 1u : 0u);
@@ -1351,7 +1351,8 @@ namespace
         if (sharded && c->n_total > c->n_local &&
             (rc = recentre_order(c, c->h_sums + kApplyAt)) != ICP_HIP_OK)
             return rc;
-        loop_init_step(&st, c->h_sums + kApplyAt, mu_m, threshold, cap_iters, (double)c->n_total);
+        loop_init_step(&st, c->h_sums + kApplyAt, mu_m, threshold, cap_iters, (double)c->n_total,
+                       sharded);
         c->first_sums_valid = false; // the loop moves the cloud
         const uint32_t g_ap = c->small ? 1u : g_st;
 

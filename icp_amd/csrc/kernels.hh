@@ -68,9 +68,11 @@ namespace icp_dev
         float T[16];     // accumulated transform (icp.cc:121)
         float Tn[12];    // rows 0..2 of this iteration's transform, read by apply_error_kernel
         float mu_p[3];   // centroid of the cloud to move (icp.cc:114), used by the solve (:57)
-        float mu_q[3];   // what the NN kernel subtracts from p (:115): mu_p in the first iteration,
-                         // mu_m afterwards (t = mu_m - r mu_p puts the moved centroid on mu_m up to
-                         // fp32 rounding, so the next pass needs no sum of the moved cloud first)
+        float mu_q[3];   // what the NN kernel subtracts from p (:115).  One GPU: mean(p) of the
+                         // cloud as it stands, every iteration, as the reference (:114-115).
+                         // Sharded: mean(p) in the first iteration, mu_m afterwards (t = mu_m -
+                         // r mu_p puts the moved centroid on mu_m up to fp32 rounding, so the next
+                         // pass can start before the moved cloud has been summed over the ranks)
         float mu_m[3];
         float error;     // icp.cc:123
         float threshold;
@@ -78,6 +80,7 @@ namespace icp_dev
         uint32_t started; // iterations solved and applied; started - it is 0 or 1
         uint32_t max_iters;
         uint32_t done;
+        uint32_t sharded; // 1: one collective per iteration (mu_q rule above, loop_advance_step)
         double n_total;
         double work[3];  // reference-traversal counters summed over the iterations (sums 9..11)
         float errors[kLoopBlockMax]; // error after iteration i at [i % kLoopBlockMax]
@@ -179,7 +182,8 @@ namespace icp_dev
                                  int tail = 0);
     // loop.hip: single-thread steps of the device-resident loop
     hipError_t launch_loop_init(LoopState* st, const double* sums, const float mu_m[3],
-                                float threshold, uint32_t max_iters, double n_total, hipStream_t s);
+                                float threshold, uint32_t max_iters, double n_total, bool sharded,
+                                hipStream_t s);
     // sums = the kIterSums doubles of one iteration (all-reduced): finish the iteration whose apply
     // pass is pending, if any, then solve the next one unless the loop is over
     hipError_t launch_loop_advance(LoopState* st, const double* sums, hipStream_t s);

@@ -27,12 +27,12 @@ namespace icp_dev
     {
         __global__ void loop_init_kernel(LoopState* st, const double* sums, float mx, float my,
                                          float mz, float threshold, uint32_t max_iters,
-                                         double n_total)
+                                         double n_total, bool sharded)
         {
             if (threadIdx.x != 0 || blockIdx.x != 0)
                 return;
             const float mu_m[3] = {mx, my, mz};
-            loop_init_step(st, sums, mu_m, threshold, max_iters, n_total);
+            loop_init_step(st, sums, mu_m, threshold, max_iters, n_total, sharded);
         }
 
         __global__ void loop_advance_kernel(LoopState* st, const double* sums)
@@ -43,10 +43,11 @@ namespace icp_dev
     } // namespace
 
     hipError_t launch_loop_init(LoopState* st, const double* sums, const float mu_m[3],
-                                float threshold, uint32_t max_iters, double n_total, hipStream_t s)
+                                float threshold, uint32_t max_iters, double n_total, bool sharded,
+                                hipStream_t s)
     {
         hipLaunchKernelGGL(loop_init_kernel, dim3(1), dim3(64), 0, s, st, sums, mu_m[0], mu_m[1],
-                           mu_m[2], threshold, max_iters, n_total);
+                           mu_m[2], threshold, max_iters, n_total, sharded);
         return hipGetLastError();
     }
     hipError_t launch_loop_advance(LoopState* st, const double* sums, hipStream_t s)

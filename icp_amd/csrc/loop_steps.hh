@@ -14,7 +14,8 @@ namespace icp_dev
     // (`sums` = kApplySums doubles)
     __host__ __device__ inline void loop_init_step(LoopState* st, const double* sums,
                                                    const float mu_m[3], float threshold,
-                                                   uint32_t max_iters, double n_total)
+                                                   uint32_t max_iters, double n_total,
+                                                   bool sharded)
     {
         for (int i = 0; i < 16; ++i)
             st->T[i] = (i % 5 == 0) ? 1.0f : 0.0f;
@@ -32,6 +33,7 @@ namespace icp_dev
         st->started = 0;
         st->max_iters = max_iters;
         st->done = (max_iters > 0u && inf > threshold) ? 0u : 1u;
+        st->sharded = sharded ? 1u : 0u;
         st->n_total = n_total;
         st->work[0] = st->work[1] = st->work[2] = 0.0;
         for (int i = 0; i < kLoopBlockMax; ++i)
@@ -63,11 +65,13 @@ namespace icp_dev
         st->work[0] += sums[9];
         st->work[1] += sums[10];
         st->work[2] += sums[11];
-        // t = mu_m - r mu_p puts the centroid of the moved cloud on mu_m (up to fp32 rounding):
-        // that is what the next NN pass subtracts, whether or not this iteration's apply pass
-        // has been summed by then (sharded runs start the pass before)
-        for (int k = 0; k < 3; ++k)
-            st->mu_q[k] = st->mu_m[k];
+        // Sharded runs start the next NN pass before this iteration's apply pass has been summed
+        // over the ranks: t = mu_m - r mu_p puts the centroid of the moved cloud on mu_m (up to
+        // fp32 rounding), and that is what the pass subtracts there.  On one GPU the sums are at
+        // hand first and loop_finish_step sets mean(new_p), as the reference does (icp.cc:114).
+        if (st->sharded)
+            for (int k = 0; k < 3; ++k)
+                st->mu_q[k] = st->mu_m[k];
         st->started += 1u;
     }
 
@@ -80,6 +84,9 @@ namespace icp_dev
         const float error = (float)sums[0];
         for (int k = 0; k < 3; ++k)
             st->mu_p[k] = (float)(sums[1 + k] / st->n_total);
+        if (!st->sharded) // mu_p = mean(new_p); p_centered = new_p - mu_p (icp.cc:114-115)
+            for (int k = 0; k < 3; ++k)
+                st->mu_q[k] = st->mu_p[k];
         st->error = error;
         st->errors[st->it % (uint32_t)kLoopBlockMax] = error;
         const uint32_t it = st->it + 1u;

@@ -14,10 +14,11 @@ extern "C"
     unsigned ls_iter_sums() { return (unsigned)kIterSums; }
     unsigned ls_apply_at() { return (unsigned)kApplyAt; }
     void ls_init(void* st, const double* sums4, const float* mu_m, float threshold,
-                 unsigned max_iters, double n_total)
+                 unsigned max_iters, double n_total, int sharded)
     {
         std::memset(st, 0, sizeof(LoopState));
-        loop_init_step(static_cast<LoopState*>(st), sums4, mu_m, threshold, max_iters, n_total);
+        loop_init_step(static_cast<LoopState*>(st), sums4, mu_m, threshold, max_iters, n_total,
+                       sharded != 0);
     }
     void ls_solve(void* st, const double* sums12) { loop_solve_step(static_cast<LoopState*>(st), sums12); }
     void ls_finish(void* st, const double* sums4) { loop_finish_step(static_cast<LoopState*>(st), sums4); }

@@ -82,15 +82,19 @@ def test_short_or_unfinished_registrations_are_left_alone(monkeypatch, world):
 def test_resort_under_a_communicator_equals_the_plain_run(monkeypatch, world):
     """With an RCCL communicator (one rank here) the loop condition is known one slot late, and
     the second ordering pass is decided from `started`, not `it`: the same iteration triggers it
-    as without a communicator, so the two runs are bit-identical."""
+    as in the host-driven run of the same sharded protocol (an all-reduce callback with nobody
+    to add), so the two runs are bit-identical; the one-GPU loop (queries centred on mean(new_p)
+    instead of mu_m) agrees within the centroid's rounding."""
     from icp_amd import capi
     monkeypatch.delenv("ICP_HIP_RESORT", raising=False)
     res = []
-    for use_comm in (False, True):
+    for mode in ("callback", "rccl", "one GPU"):
         with capi.Context() as ctx:
             ctx.build_tree(world["mc"], 256)
-            if use_comm:
+            if mode == "rccl":
                 ctx.comm_init_rank(1, 0, capi.Context.comm_unique_id())
+            elif mode == "callback":
+                ctx.set_allreduce(lambda a: None)
             ctx.set_queries(world["p"])
             errs = []
             T, it, err = ctx.run(world["mu_m"], 16, 0.0, progress=lambda i, mx, e: errs.append(e))
@@ -98,6 +102,8 @@ def test_resort_under_a_communicator_equals_the_plain_run(monkeypatch, world):
     assert res[0][1] == res[1][1] == 16 and res[0][3] == res[1][3]
     assert (bits(res[0][0]) == bits(res[1][0])).all()
     assert (bits(res[0][4]) == bits(res[1][4])).all()
+    assert res[2][1] == 16 and np.abs(res[2][0] - res[1][0]).max() <= 1e-6
+    assert np.abs(res[2][4] - res[1][4]).max() <= 1e-6
 
 
 def test_many_rank_rule_decides_from_nothing_a_single_rank_sees(monkeypatch, world):

@@ -6,8 +6,14 @@ around the oracle's NN pass, in both orders the product uses:
   sharded   NN(k) -> ONE all-reduce of 16 doubles [NN sums of k | apply sums of k-1]
                   -> advance = finish(k-1), solve(k) -> apply(k)            k iterations = k + 1 slots
 
-The sums are added exactly (math.fsum), so the two orders and any split into shards must give
-the same bits; the CPU path (oracle.icp) must agree on the iteration count and within 1e-5 on T.
+What the NN pass subtracts: on one GPU mean(p) of the cloud as it stands, every iteration, as the
+reference does (icp.cc:114-115); a sharded state (LoopState::sharded) takes mu_m from the second
+iteration on, because its pass starts before the moved cloud has been summed over the ranks.
+
+The sums are added exactly (math.fsum), so a sharded state stepped in either order and any split
+into shards must give the same bits; the one-GPU state must agree with the CPU path (oracle.icp)
+on the iteration count and within 1e-5 on T, and differ from the sharded one by no more than the
+rounding of the centroid.
 """
 import ctypes as C
 import math
@@ -39,7 +45,7 @@ def ls():
             pytest.skip("no HIP headers to build the harness with")
         build_harness()
     lib = C.CDLL(SO)
-    lib.ls_init.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_uint, C.c_double]
+    lib.ls_init.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_uint, C.c_double, C.c_int]
     for f in (lib.ls_solve, lib.ls_finish, lib.ls_advance):
         f.argtypes = [C.c_void_p, C.c_void_p]
     lib.ls_nn_idle.argtypes = [C.c_void_p]
@@ -49,11 +55,12 @@ def ls():
 
 
 class State:
-    def __init__(self, lib, sums4, mu_m, thr, cap, n_total):
+    def __init__(self, lib, sums4, mu_m, thr, cap, n_total, sharded):
         self.lib = lib
         self.buf = C.create_string_buffer(lib.ls_state_size())
         s = np.asarray(sums4, np.float64)
-        lib.ls_init(self.buf, s.ctypes.data, np.asarray(mu_m, np.float32).ctypes.data, thr, cap, float(n_total))
+        lib.ls_init(self.buf, s.ctypes.data, np.asarray(mu_m, np.float32).ctypes.data, thr, cap, float(n_total),
+                    int(sharded))
 
     def call(self, fn, sums):
         s = np.ascontiguousarray(sums, np.float64)
@@ -97,12 +104,19 @@ def apply_terms(p, y, Tn, mu_m):
     return new, np.concatenate([err[:, None], new], axis=1).astype(np.float64)
 
 
-def run_plain(lib, oracle, otree, p, mu_m, cap, thr):
-    st = State(lib, [0.0] + fsum_cols(p), mu_m, thr, cap, len(p))
+def run_plain(lib, oracle, otree, p, mu_m, cap, thr, sharded):
+    st = State(lib, [0.0] + fsum_cols(p), mu_m, thr, cap, len(p), sharded)
     p = p.copy()
     errors = []
     while not st.get()["done"]:
-        terms, y = nn_terms(oracle, otree, p, st.get()["mu_q"])
+        mu_q = st.get()["mu_q"]
+        mean_p = (np.array(fsum_cols(p)) / float(len(p))).astype(np.float32)
+        if not sharded or not errors:       # mean(new_p), icp.cc:114
+            assert (mu_q.view(np.uint32) == mean_p.view(np.uint32)).all()
+        else:                               # mu_m, where t = mu_m - r mu_p has put the centroid
+            assert (mu_q.view(np.uint32) == np.asarray(mu_m, np.float32).view(np.uint32)).all()
+            assert np.abs(mean_p - mu_q).max() <= 3e-7 * max(1.0, np.abs(p).max())
+        terms, y = nn_terms(oracle, otree, p, mu_q)
         st.call(lib.ls_solve, fsum_cols(terms))
         p, at = apply_terms(p, y, st.get()["Tn"], mu_m)
         st.call(lib.ls_finish, fsum_cols(at))
@@ -112,7 +126,7 @@ def run_plain(lib, oracle, otree, p, mu_m, cap, thr):
 
 def run_sharded(lib, oracle, otree, p, mu_m, cap, thr, cuts):
     shards = [p[a:b].copy() for a, b in zip([0] + cuts, cuts + [len(p)])]
-    st = State(lib, [0.0] + fsum_cols(p), mu_m, thr, cap, len(p))
+    st = State(lib, [0.0] + fsum_cols(p), mu_m, thr, cap, len(p), True)
     pending = [0.0] * 4          # apply sums of the iteration before (zeros in the first slot)
     slots = 0
     errors = []
@@ -145,7 +159,11 @@ def test_both_orders_give_the_same_bits(ls, oracle, clouds, pair, capacity, cap_
     m, p = clouds["cow_ref"], clouds[pair]
     mu_m = oracle.mean(m)
     otree = oracle.tree_build(capacity, oracle.subtract(m, mu_m))
-    a, pa, ea, _ = run_plain(ls, oracle, otree, p, mu_m, cap_iters, thr)
+    ref, pref, eref, _ = run_plain(ls, oracle, otree, p, mu_m, cap_iters, thr, False)
+    a, pa, ea, _ = run_plain(ls, oracle, otree, p, mu_m, cap_iters, thr, True)
+    # the two centring rules: same iteration count, the same transform up to the centroid's rounding
+    assert ref["it"] == a["it"] and np.abs(ref["T"] - a["T"]).max() <= 2e-6
+    assert np.abs(pref - pa).max() <= 2e-6 * max(1.0, np.abs(pa).max())
     for cuts in ([1000], [5, 2000, 2001]):      # two shards; four, one of them a single point
         b, pb, eb, slots = run_sharded(ls, oracle, otree, p, mu_m, cap_iters, thr, list(cuts))
         assert a["it"] == b["it"] and ea == eb
@@ -156,9 +174,10 @@ def test_both_orders_give_the_same_bits(ls, oracle, clouds, pair, capacity, cap_
         assert slots == (a["it"] + 1 if a["it"] else 0)
     if thr == 1e-5 and cap_iters == 200:
         cpu = oracle.icp(m, p, cap_iters, thr, capacity)
-        assert a["it"] == cpu["iterations"]
-        assert np.abs(a["T"] - cpu["T"]).max() <= 1e-5
-        assert np.abs(pa - m).max() < 5e-3          # test_functionnal.cc's tolerance
+        for got, moved in ((ref, pref), (a, pa)):
+            assert got["it"] == cpu["iterations"]
+            assert np.abs(got["T"] - cpu["T"]).max() <= 1e-5
+            assert np.abs(moved - m).max() < 5e-3          # test_functionnal.cc's tolerance
     else:
         assert a["it"] == (0 if (cap_iters == 0 or thr == float("inf")) else cap_iters)
         if a["it"] == 0:
