@@ -20,7 +20,7 @@ class Hip:
     def __init__(self):
         from icp_amd import capi
         capi.load()  # libicp_hip.so brings the runtime in
-        self.rt = C.CDLL("libamdhip64.so.7")
+        self.rt = self._runtime()
         self.rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
         self.rt.hipFree.argtypes = [C.c_void_p]
         self.rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
@@ -30,6 +30,17 @@ class Hip:
         self.rt.hipStreamDestroy.argtypes = [C.c_void_p]
         self.rt.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         self.bufs = []
+
+    @staticmethod
+    def _runtime():
+        """The HIP runtime libicp_hip.so is linked against (whatever its soname on this ROCm)."""
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.split()[-1]
+                if "libamdhip64.so" in path:
+                    return C.CDLL(path)
+        import ctypes.util
+        return C.CDLL(ctypes.util.find_library("amdhip64") or "libamdhip64.so")
 
     def ok(self, rc):
         assert rc == 0, f"HIP error {rc}"
@@ -99,9 +110,11 @@ def _run_noalloc(hip, ctx, p, mu_p, stream):
     ctx.nn_noalloc(px, py, pz, n, mu_p, row, dist, y[0], y[1], y[2], sums, stream)
     hip.sync(stream)
     # nothing was allocated on the device (the first launch of a kernel in a process is left
-    # out: the HIP runtime may then set up the hardware queue's private segment)
+    # out: the HIP runtime may then set up the hardware queue's private segment).  Free memory
+    # may GROW across the call: the runtime hands back, at a synchronisation, blocks that
+    # contexts destroyed by earlier tests had released (seen: +2 MiB after other test files).
     if _warm:
-        assert hip.free_bytes() == free_before
+        assert hip.free_bytes() >= free_before
     _warm.append(1)
     out = dict(row=hip.download(row, np.uint32, n), dist=hip.download(dist, np.float32, n),
                xyz=np.stack([hip.download(t, np.float32, n) for t in y], 1),
