@@ -307,6 +307,22 @@ struct icp_hip_ctx
     uint32_t batch_queries = 64; // queries per wave-batch of nn_tile_kernel (prepare_tile)
     bool tile_ready = false;
     uint32_t tile_cut = 4; // in 16ths; ICP_HIP_TILE_CUT overrides (0 = run the node phase to the end)
+    // stragglers of nn_tile_kernel (nn_tile.hip): one lot per resident wave, late rows per chunk
+    DevBuf<uint32_t> park, late, late_cnt;
+    // When: measured on one MI355X (scripts/park_probe.py, bench.py): once the clouds are aligned
+    // the pass is 9-13 % faster from 16M points up, 3 % at 8M, and SLOWER below (every wave ends
+    // with a batch of what is left in its lot, which weighs on a short pass); while the clouds
+    // are still a point spacing apart it is 5 % faster at 64M points and 9 % slower at 16M.  So
+    // the lots are used on shards of kParkMinPoints and more, in the passes after the second
+    // ordering pass (maybe_resort: the registration's own sign that the clouds are aligned).
+    // ICP_HIP_PARK=always / never overrides (tests, experiments).
+    uint32_t park_max = 8;        // ICP_HIP_PARK_MAX
+    uint32_t park_wait = 0;       // ICP_HIP_PARK_WAIT
+    uint32_t late_per_batch = 2;  // ICP_HIP_LATE_PER_BATCH: late rows of a chunk = this x its batches
+    int park_mode = 0;            // 0: the rule above, 1: always, 2: never
+    bool park_ready = false;      // lots and late rows are allocated for the current launch shape
+    bool park_now() const { return park_ready && (park_mode == 1 || resorted); }
+    uint32_t late_rows() const { return late_per_batch * chunk_batches; }
 
     icp_hip_allreduce_fn allreduce = nullptr;
     void* allreduce_user = nullptr;
@@ -429,6 +445,8 @@ namespace
         return a;
     }
 
+    constexpr uint64_t kParkMinPoints = 6'000'000; // shards from which the straggler lots pay
+
     // Size the tile kernel's launch for the current tree + shard (called when either changes;
     // allocates, so never from the iteration loop).
     int prepare_tile(icp_hip_ctx* c)
@@ -465,6 +483,19 @@ namespace
             const char* env = std::getenv("ICP_HIP_TILE_STATS");
             if (env && env[0] == '1')
                 HIP_TRY(c, c->stats.alloc((size_t)kTileStatsWords * kTileStatsCopies));
+        }
+        // (a small shard runs a handful of batches: nothing to gather in a lot)
+        c->park_ready = false;
+        if (!c->small && c->park_max != 0 && c->batch_queries == 64 && c->park_mode != 2 &&
+            (c->park_mode == 1 || c->n_local >= kParkMinPoints))
+        {
+            HIP_TRY(c, c->park.alloc((size_t)c->tile_grid_blocks * 4 * 2 * kParkLotWords));
+            // late rows: late_per_batch per batch however the batches are cut into chunks
+            // (maybe_resort makes the chunks larger later; a last partial chunk rounds up)
+            const uint64_t batches = (c->n_local + c->batch_queries - 1) / c->batch_queries;
+            HIP_TRY(c, c->late.alloc((size_t)(batches + 64) * c->late_per_batch * kCovSums));
+            HIP_TRY(c, c->late_cnt.alloc(c->n_chunks));
+            c->park_ready = true;
         }
         HIP_TRY(c, c->chunk_sums.alloc((size_t)c->n_chunks * kCovSums));
         HIP_TRY(c, c->spill.alloc((size_t)c->spill_levels * c->tile_grid_blocks * 256));
@@ -513,6 +544,16 @@ namespace
         a.grid = c->tile_grid_blocks;
         TileLaunch q{c->chunk_batches, c->batch_queries, c->chunk_sums.p, c->queue.p,
                      c->spill.p, loop ? nullptr : c->stats.p, c->tile_cut};
+        const bool park = c->park_now();
+        if (park)
+        {
+            q.park = c->park.p;
+            q.late = c->late.p;
+            q.late_cnt = c->late_cnt.p;
+            q.late_rows = c->late_rows();
+            q.park_max = c->park_max;
+            q.park_wait = c->park_wait;
+        }
         if (q.stats)
             HIP_TRY(c, hipMemsetAsync(q.stats, 0,
                                       sizeof(unsigned long long) * kTileStatsWords * kTileStatsCopies,
@@ -580,8 +621,13 @@ namespace
             }
         }
         // chunk sums (-> <= 1024 partial rows) -> the twelve sums, in a fixed order
-        HIP_TRY(c, launch_chunk_sums(c->chunk_sums.p, c->n_chunks, c->partials.p, c->sums.p,
-                                     c->stream, loop, tail));
+        if (park)
+            HIP_TRY(c, launch_chunk_sums_late(c->chunk_sums.p, c->n_chunks, c->late.p, c->late_cnt.p,
+                                              c->late_rows(), c->partials.p, c->sums.p, c->stream,
+                                              loop, tail));
+        else
+            HIP_TRY(c, launch_chunk_sums(c->chunk_sums.p, c->n_chunks, c->partials.p, c->sums.p,
+                                         c->stream, loop, tail));
         return ICP_HIP_OK;
     }
 
@@ -1661,6 +1707,15 @@ extern "C"
             const char* cut = std::getenv("ICP_HIP_TILE_CUT");
             if (cut)
                 c->tile_cut = (uint32_t)std::atoi(cut);
+            if (const char* pk = std::getenv("ICP_HIP_PARK"))
+                c->park_mode = std::strcmp(pk, "always") == 0 ? 1
+                               : (std::strcmp(pk, "never") == 0 || std::strcmp(pk, "0") == 0) ? 2 : 0;
+            if (const char* pm = std::getenv("ICP_HIP_PARK_MAX"))
+                c->park_max = std::min((uint32_t)std::max(0, std::atoi(pm)), kParkMaxLanes);
+            if (const char* pw = std::getenv("ICP_HIP_PARK_WAIT"))
+                c->park_wait = std::min((uint32_t)std::max(0, std::atoi(pw)), 255u);
+            if (const char* lb = std::getenv("ICP_HIP_LATE_PER_BATCH"))
+                c->late_per_batch = std::min((uint32_t)std::max(1, std::atoi(lb)), 32u);
         }
         *out = c;
         return ICP_HIP_OK;
@@ -1695,6 +1750,9 @@ extern "C"
         c->perm.release();
         c->queue.release();
         c->chunk_sums.release();
+        c->park.release();
+        c->late.release();
+        c->late_cnt.release();
         c->spill.release();
         c->stats.release();
         c->partials.release();

@@ -131,7 +131,20 @@ namespace icp_dev
         unsigned long long* stats; // kTileStatsWords x kTileStatsCopies counters of the diagnostic build
                                    // (events, cycles by phase, histograms), or null
         uint32_t cut; // leave the node phase when waiting lanes >= cut/16 x stepping lanes (0: never)
+        // Stragglers (nn_tile.hip): the last <= park_max lanes at work in a batch move to the
+        // wave's lot in `park` and are run later, a batch of them together; their terms go to
+        // late rows (kCovSums words each: nine fp32 products, three integer counters), late_rows
+        // per chunk, of which late_cnt[chunk] are in use after the launch.  park null: off.
+        uint32_t* park = nullptr;     // [grid * 4 waves][kParkLotWords] or null
+        uint32_t* late = nullptr;     // [n_chunks][late_rows][kCovSums]
+        uint32_t* late_cnt = nullptr; // [n_chunks]
+        uint32_t late_rows = 0;
+        uint32_t park_max = 0;
+        uint32_t park_wait = 0; // rounds (node + leaf phase) a batch goes on with <= park_max lanes
+                                // at work before it parks them: short excursions end in place
     };
+    constexpr uint32_t kParkLotWords = 64 * 22; // words of ONE lot; a wave has two (nn_tile.hip asserts the size)
+    constexpr uint32_t kParkMaxLanes = 32;
     hipError_t launch_nn_tile(const NnLaunch& a, const TileLaunch& q, hipStream_t s);
     // How a shard of n queries is laid on a grid of at most max_blocks resident workgroups.
     struct TilePlan
@@ -180,6 +193,12 @@ namespace icp_dev
     hipError_t launch_chunk_sums(const double* chunk_sums, uint32_t n_chunks, double* partials,
                                  double* out, hipStream_t s, LoopState* loop = nullptr,
                                  int tail = 0);
+    // the same with the late rows of the chunks' parked queries (TileLaunch): every chunk's row
+    // of chunk_sums, then its late_cnt[chunk] late rows, in a fixed order; always two launches
+    hipError_t launch_chunk_sums_late(const double* chunk_sums, uint32_t n_chunks,
+                                      const uint32_t* late, const uint32_t* late_cnt,
+                                      uint32_t late_rows, double* partials, double* out,
+                                      hipStream_t s, LoopState* loop = nullptr, int tail = 0);
     // loop.hip: single-thread steps of the device-resident loop
     hipError_t launch_loop_init(LoopState* st, const double* sums, const float mu_m[3],
                                 float threshold, uint32_t max_iters, double n_total, bool sharded,

@@ -393,6 +393,42 @@ namespace icp_dev
         }
     }
 
+    // The same with late rows (nn_tile.hip, stragglers): chunk r adds its row of `rows` and then
+    // its late_cnt[r] rows of `late` (nine fp32 products, three integer counters per row).
+    __global__ void __launch_bounds__(kBlock)
+        reduce_rows_late_kernel(const double* __restrict__ rows, uint32_t n_rows, uint32_t per,
+                                const uint32_t* __restrict__ late,
+                                const uint32_t* __restrict__ late_cnt, uint32_t late_rows,
+                                double* __restrict__ out)
+    {
+        __shared__ double s[16][17];
+        const int col = threadIdx.x & 15, rl = threadIdx.x >> 4;
+        const uint32_t begin = blockIdx.x * per;
+        const uint32_t end = min(begin + per, n_rows);
+        double v = 0.0;
+        if (col < kCovSums)
+            for (uint32_t r = begin + rl; r < end; r += 16)
+            {
+                v += rows[(size_t)r * kCovSums + col];
+                const uint32_t cnt = min(late_cnt[r], late_rows);
+                const uint32_t* lr = late + (size_t)r * late_rows * kCovSums + col;
+                for (uint32_t k = 0; k < cnt; ++k)
+                {
+                    const uint32_t w = lr[(size_t)k * kCovSums];
+                    v += col < 9 ? (double)__uint_as_float(w) : (double)w;
+                }
+            }
+        s[rl][col] = v;
+        __syncthreads();
+        if (threadIdx.x < (uint32_t)kCovSums)
+        {
+            double tot = 0.0;
+            for (int j = 0; j < 16; ++j)
+                tot += s[j][threadIdx.x];
+            out[(size_t)blockIdx.x * kCovSums + threadIdx.x] = tot;
+        }
+    }
+
     __global__ void __launch_bounds__(kBlock)
         aos_to_soa_kernel(const float* __restrict__ aos, uint32_t n, float* __restrict__ x,
                           float* __restrict__ y, float* __restrict__ z)
@@ -587,6 +623,24 @@ namespace icp_dev
         uint32_t g1 = (n_chunks + 63) / 64;
         g1 = g1 > 1024 ? 1024 : g1;
         hipError_t e = launch_reduce_rows(chunk_sums, n_chunks, kCovSums, g1, partials, s);
+        if (e != hipSuccess)
+            return e;
+        return launch_reduce_partials(partials, g1, kCovSums, out, s, loop, tail);
+    }
+
+    hipError_t launch_chunk_sums_late(const double* chunk_sums, uint32_t n_chunks,
+                                      const uint32_t* late, const uint32_t* late_cnt,
+                                      uint32_t late_rows, double* partials, double* out,
+                                      hipStream_t s, LoopState* loop, int tail)
+    {
+        if (n_chunks == 0 || !late || !late_cnt)
+            return hipErrorInvalidValue;
+        uint32_t g1 = (n_chunks + 63) / 64;
+        g1 = g1 > 1024 ? 1024 : g1;
+        const uint32_t per = (n_chunks + g1 - 1) / g1;
+        hipLaunchKernelGGL(reduce_rows_late_kernel, dim3(g1), dim3(kBlock), 0, s, chunk_sums, n_chunks,
+                           per, late, late_cnt, late_rows, partials);
+        const hipError_t e = hipGetLastError();
         if (e != hipSuccess)
             return e;
         return launch_reduce_partials(partials, g1, kCovSums, out, s, loop, tail);

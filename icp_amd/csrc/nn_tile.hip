@@ -66,6 +66,16 @@ namespace icp_dev
         constexpr int kImage = 256; // bucket slots staged per window
         constexpr int kGroups = kImage / 4; // float4 groups of the image; group kGroups is +inf
         constexpr int kTileMinGroup = 4; // fewer lanes on a bucket: whole-wave scan per lane
+        // ---- the parking lot (see "stragglers" in the kernel) ----
+        constexpr uint32_t kLot = 64;       // entries per wave: one batch of parked queries
+        enum : uint32_t
+        {
+            pkQx = 0, pkQy, pkQz, pkNode, pkPrev, pkModeSp, pkRd, pkRid, pkChainM, pkChainM2, pkArg,
+            pkRetNode, pkTop, pkNInt, pkNPts, pkOvf, pkIndex, pkRow, pkStD0, pkStI0, pkStD1, pkStI1,
+            kParkWords
+        };
+        static_assert(kStackK == 2, "the lot keeps two stack entries per parked lane");
+        static_assert(kLot * kParkWords == kParkLotWords, "kernels.hh sizes the lots");
         constexpr int kTileSplitBelow = 56; // 33..55 lanes: scan as 32 + rest (see the leaf phase)
 
         enum : int
@@ -484,20 +494,63 @@ namespace icp_dev
 
     } // namespace
 
+        // The kernel's arguments as ONE structure.  What the batches use (the tree, the clouds,
+        // the matched points, the centroid, the sizes of a batch) is read once and lives in
+        // SGPRs; what is needed once per chunk or only when a query is parked, spilled or
+        // reported (the queue, the chunk sums, the lots and late rows, the overflow stack, rows
+        // and distances) is read from the kernel-argument segment where it is used, through a
+        // pointer the compiler cannot see through: kept in registers across the kernel they
+        // pushed the scalar registers past what the wave has (89 spilled, into the hot loops).
+        // (Reading EVERYTHING there, the clouds and outputs of every batch included, removed 52
+        // of the 62 spills of the kernel before the lots and was 0.7 % slower: a v_readlane at
+        // the head of a batch is cheaper than a scalar load and its wait.)
+        struct TileArgs
+        {
+            DevTree t;
+            const float *px, *py, *pz;
+            float mux, muy, muz;
+            uint32_t n;
+            float *yx, *yy, *yz;
+            uint32_t cut, batch_queries, park_max, want_rows; // want_rows: row_out or dist_out set
+            // ---- read where they are used ----
+            uint32_t* row_out;
+            float* dist_out;
+            const uint32_t* perm;
+            double* chunk_sums;
+            uint32_t* queue;
+            uint2* spill;
+            uint32_t n_batches, chunk_batches, n_chunks, late_rows;
+            uint32_t *park, *late, *late_cnt;
+            unsigned long long* stats;
+            const LoopState* loop;
+        };
+        typedef const __attribute__((address_space(4))) TileArgs* tile_args_ptr;
+
         template <bool STATS>
         __global__ void __launch_bounds__(kBlock, 7) // 7 workgroups per CU (LDS 7 x 20.7 KiB, <= 72 VGPRs)
-            nn_tile_kernel(DevTree t, const float* __restrict__ px, const float* __restrict__ py,
-                           const float* __restrict__ pz, float mux, float muy, float muz, uint32_t n,
-                           float* __restrict__ yx, float* __restrict__ yy, float* __restrict__ yz,
-                           uint32_t* __restrict__ row_out, float* __restrict__ dist_out,
-                           const uint32_t* __restrict__ perm, double* __restrict__ chunk_sums,
-                           uint32_t* __restrict__ queue, uint2* __restrict__ spill,
-                           uint32_t n_batches, uint32_t chunk_batches, uint32_t n_chunks,
-                           uint32_t cut, uint32_t batch_queries,
-                           unsigned long long* __restrict__ stats,
-                           const LoopState* __restrict__ loop)
+            nn_tile_kernel(const TileArgs args)
         {
             __shared__ WaveLds s_w[kWavesPerBlock];
+            // (explicit arguments start at offset 0 of the kernel-argument segment)
+            auto cold = [&]() -> tile_args_ptr {
+                tile_args_ptr p = (tile_args_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+                asm volatile("" : "+s"(p));
+                return p;
+            };
+            const DevTree t = {args.t.nodes, args.t.leaf_info, args.t.sx, args.t.sy, args.t.sz, nullptr,
+                               nullptr, args.t.ring, args.t.n_slots, args.t.n_nodes, args.t.root};
+            const float* __restrict__ px = args.px;
+            const float* __restrict__ py = args.py;
+            const float* __restrict__ pz = args.pz;
+            float* __restrict__ yx = args.yx;
+            float* __restrict__ yy = args.yy;
+            float* __restrict__ yz = args.yz;
+            float mux = args.mux, muy = args.muy, muz = args.muz;
+            const uint32_t n = args.n, cut = args.cut, batch_queries = args.batch_queries;
+            const uint32_t park_max = args.park_max & 0xFFu; // 0: no lots
+            const uint32_t park_wait = args.park_max >> 8;   // rounds a batch goes on before it parks
+            const LoopState* loop = cold()->loop;
+            unsigned long long* stats = STATS ? cold()->stats : nullptr;
             if (loop)
             {
                 // device-resident loop (loop.hip): the centroid comes from the previous
@@ -505,9 +558,10 @@ namespace icp_dev
                 // (or has started its last iteration and only waits for that one's error)
                 if (loop->done || loop->started >= loop->max_iters)
                     return;
-                mux = loop->mu_q[0];
-                muy = loop->mu_q[1];
-                muz = loop->mu_q[2];
+                // (wave-uniform: kept in SGPRs)
+                mux = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(loop->mu_q[0])));
+                muy = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(loop->mu_q[1])));
+                muz = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(loop->mu_q[2])));
             }
             // wave-level event counts of the diagnostic build (ICP_HIP_TILE_STATS=1)
             uint32_t st_node = 0, st_tile = 0, st_tile_g = 0, st_tile_len = 0, st_coop = 0,
@@ -545,58 +599,125 @@ namespace icp_dev
             // this lane's column of the overflow stack: entry e at spill_col[e * spill_stride]
             // (made where it is used, from a thread index the compiler cannot see through: kept
             // across the kernel the address was one of the registers that spilled to scratch)
-            const size_t spill_stride = (size_t)gridDim.x * kBlock;
             auto spill_at = [&](uint32_t e) -> uint2* {
                 uint32_t tid = threadIdx.x;
                 asm volatile("" : "+v"(tid));
-                return spill + ((size_t)blockIdx.x * kBlock + tid + (size_t)e * spill_stride);
+                const size_t spill_stride = (size_t)gridDim.x * kBlock;
+                return cold()->spill + ((size_t)blockIdx.x * kBlock + tid + (size_t)e * spill_stride);
             };
 
+            // ---- stragglers: the parking lot ----
+            // Once the clouds are aligned 99 % of the lanes of a batch are finished by their first
+            // bucket; the few that are not (a query whose answer lies on a node's centre or on
+            // its sphere: the reference searches that node's far side, vp-tree.cc:152-160) used
+            // to keep the whole wave stepping through nodes for one or two lanes -- a batch with
+            // one cost three times a batch without, and 29 % of the batches had one.  Now the
+            // lanes that are still at work when at most `park_max` of a batch are, put their
+            // whole traversal state into the wave's lot in HBM and the batch ends without them;
+            // when the lot holds a batch worth of parked queries (or the queues are empty) the
+            // wave runs them together as one more batch, from wherever each of them stood.  The
+            // traversal of a query is untouched: it only continues in another lane, later.
+            //   Its terms go to a row of their own: chunk c owns rows [c * late_rows, (c + 1) *
+            // late_rows) of `late` (twelve words each: the nine fp32 products, the three counters
+            // as integers), hands them out in the order its batches park queries and writes how
+            // many it handed out to late_cnt[c]; the chunk-sum reduction adds row 0 (chunk_sums)
+            // and the late rows of each chunk in a fixed order.  Whether a lane is parked depends
+            // on its batch and its chunk only (how many lanes are left, how many rows the chunk
+            // has used), never on what else the wave has in its lot -- the lot is emptied before
+            // a batch that could overflow it -- so the sums stay bitwise reproducible whatever
+            // wave runs a chunk.
+            const bool park_on = park_max != 0u;
+            // (entry e of this wave's lot; made where it is used, from an index the compiler
+            // cannot see through, like spill_at below: the addresses must not be kept in
+            // registers across the kernel)
+            // A wave has TWO lots: queries are parked in lot `cur`; a flush takes all of its
+            // entries, one per lane, and makes the other lot the current one -- so the entries
+            // just taken stay intact while their batch runs, and the two words of an entry that
+            // only the end of the query needs (its index and its late row) are read from there
+            // instead of riding in registers through the batch.
+            auto lot_at = [&](uint32_t which, uint32_t e) -> uint32_t* {
+                uint32_t tid = threadIdx.x;
+                asm volatile("" : "+v"(tid));
+                return cold()->park +
+                       ((size_t)((blockIdx.x * (uint32_t)kWavesPerBlock + (tid >> 6)) * 2u + which) * (kLot * kParkWords) + e);
+            };
+            uint32_t cur = 0; // wave-uniform: the lot that takes parked queries
+            uint32_t lot = 0;     // wave-uniform: entries in the lot
+            uint32_t k_chunk = 0; // wave-uniform: late rows the current chunk has handed out
+
             // XCD group x owns chunks [x*per_group, (x+1)*per_group); its head is queue[x*32]
-            const uint32_t per_group = (n_chunks + 7u) >> 3;
             uint32_t victim = 0;
             uint32_t grp_x = blockIdx.x & 7u;
+            uint32_t chunk = 0, b = 0, b_end = 0;
+            bool have_chunk = false;
             for (;;)
             {
-                // ---- pull the next chunk ----
-                const unsigned long long cy_p0 = now();
-                uint32_t chunk = 0;
-                bool have = false;
-                while (victim < 8u)
+                // ---- the next piece of work: a batch of the current chunk, or the lot ----
+                bool flush = park_on && lot + park_max > kLot;
+                if (!flush && b == b_end)
                 {
-                    const uint32_t lo = min(grp_x * per_group, n_chunks);
-                    const uint32_t hi = min(lo + per_group, n_chunks);
-                    uint32_t c = 0;
-                    if (lane == 0)
-                        c = __hip_atomic_fetch_add(queue + grp_x * 32u, 1u, __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_AGENT);
-                    c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
-                    if (c < hi - lo)
+                    if (have_chunk)
                     {
-                        chunk = lo + c;
-                        have = true;
-                        break;
+                        // the chunk's sums, and how many late rows it handed out
+                        have_chunk = false;
+                        uint32_t lane_c = (uint32_t)lane;
+                        asm volatile("" : "+v"(lane_c));
+                        tile_args_ptr A = cold();
+                        if (A->chunk_sums && lane_c < (uint32_t)kCovSums)
+                            A->chunk_sums[(size_t)chunk * kCovSums + lane_c] = L.sums[lane_c];
+                        if (park_on && lane_c == 0u)
+                            A->late_cnt[chunk] = k_chunk;
                     }
-                    victim += 1u; // this group is drained: steal from the next one
-                    grp_x = (grp_x + 1u) & 7u;
+                    // ---- pull the next chunk ----
+                    const unsigned long long cy_p0 = now();
+                    const uint32_t n_chunks = cold()->n_chunks;
+                    const uint32_t per_group = (n_chunks + 7u) >> 3;
+                    while (victim < 8u)
+                    {
+                        const uint32_t lo = min(grp_x * per_group, n_chunks);
+                        const uint32_t hi = min(lo + per_group, n_chunks);
+                        uint32_t c = 0;
+                        if (lane == 0)
+                            c = __hip_atomic_fetch_add(cold()->queue + grp_x * 32u, 1u, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT);
+                        c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+                        if (c < hi - lo)
+                        {
+                            chunk = lo + c;
+                            have_chunk = true;
+                            break;
+                        }
+                        victim += 1u; // this group is drained: steal from the next one
+                        grp_x = (grp_x + 1u) & 7u;
+                    }
+                    cy_pop += now() - cy_p0;
+                    if (have_chunk)
+                    {
+                        // (`lane_c` is opaque to the compiler so that the zero and the address of
+                        // this lane's chunk sum are made here, not kept in registers -- they were
+                        // what spilled to scratch -- across the whole kernel)
+                        uint32_t lane_c = (uint32_t)lane;
+                        asm volatile("" : "+v"(lane_c));
+                        if (lane_c < (uint32_t)kCovSums)
+                        {
+                            uint32_t z;
+                            asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+                            *reinterpret_cast<uint2*>(&L.sums[lane_c]) = make_uint2(z, z); // +0.0
+                        }
+                        b = chunk * cold()->chunk_batches;
+                        b_end = min(b + cold()->chunk_batches, cold()->n_batches);
+                        k_chunk = 0;
+                    }
+                    else
+                    {
+                        // the queues are empty: what is left is the lot, and nothing is parked again
+                        if (lot == 0)
+                            break;
+                        flush = true;
+                    }
                 }
-                cy_pop += now() - cy_p0;
-                if (!have)
-                    break;
-                // (once per chunk: `lane_c` is opaque to the compiler so that the zero and the
-                // address of this lane's chunk sum are made here, not kept in registers -- they
-                // were what spilled to scratch -- across the whole kernel)
-                uint32_t lane_c = (uint32_t)lane;
-                asm volatile("" : "+v"(lane_c));
-                if (lane_c < (uint32_t)kCovSums)
-                {
-                    uint32_t z;
-                    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
-                    *reinterpret_cast<uint2*>(&L.sums[lane_c]) = make_uint2(z, z); // +0.0
-                }
-                const uint32_t b_begin = chunk * chunk_batches;
-                const uint32_t b_end = min(b_begin + chunk_batches, n_batches);
-            for (uint32_t b = b_begin; b < b_end; ++b)
+                // a flush with the queues empty is final: its lanes run to the end in place
+                const bool final_flush = flush && !have_chunk;
             {
                 if (STATS)
                     st_batch += 1u;
@@ -605,11 +726,12 @@ namespace icp_dev
                 const unsigned long long cy_node_b0 = cy_node, cy_tile_b0 = cy_tile, cy_coop_b0 = cy_coop;
                 const uint32_t st_node_b0 = st_node, st_tile_b0 = st_tile, st_coop_b0 = st_coop,
                                st_leafph_b0 = st_leafph;
-                const uint32_t i = b * batch_queries + (uint32_t)lane;
-                const bool valid = (uint32_t)lane < batch_queries && i < n;
+                // `valid`: this lane holds a query that the end of this batch finishes
+                bool valid = !flush && (uint32_t)lane < batch_queries && b * batch_queries + (uint32_t)lane < n;
                 float qx = 0.f, qy = 0.f, qz = 0.f;
                 if (valid)
                 {
+                    const uint32_t i = b * batch_queries + (uint32_t)lane;
                     // p_centered = p - mu_p (point-3d.cc:202-206)
                     qx = __fsub_rn(px[i], mux);
                     qy = __fsub_rn(py[i], muy);
@@ -628,11 +750,46 @@ namespace icp_dev
                 float chain_m = __int_as_float(0x7f800000), chain_m2 = chain_m;
                 uint32_t sp = 0, ovf = 0;
                 uint32_t n_int = 0, n_pts = 0; // work counters of this query
+                uint32_t low_rounds = 0; // wave-uniform: rounds with no more than park_max lanes at work
                 float rd = 0.f;
                 uint32_t rid = 0;
                 uint32_t lbeg = 0, lcnt = 0;
                 cy_head += now() - cy_b0;
-                if (!valid)
+                if (flush)
+                {
+                    // the parked queries, each where it stood (one per lane, `lot` of them)
+                    valid = (uint32_t)lane < lot;
+                    mode = tDone;
+                    if (valid)
+                    {
+                        const uint32_t* e = lot_at(cur, (uint32_t)lane);
+                        qx = __uint_as_float(e[pkQx * kLot]);
+                        qy = __uint_as_float(e[pkQy * kLot]);
+                        qz = __uint_as_float(e[pkQz * kLot]);
+                        node = (int)e[pkNode * kLot];
+                        prev = (int)e[pkPrev * kLot];
+                        const uint32_t ms = e[pkModeSp * kLot];
+                        mode = (int)(ms & 0xFFu);
+                        sp = ms >> 8;
+                        rd = __uint_as_float(e[pkRd * kLot]);
+                        rid = e[pkRid * kLot];
+                        chain_m = __uint_as_float(e[pkChainM * kLot]);
+                        chain_m2 = __uint_as_float(e[pkChainM2 * kLot]);
+                        arg = (int)e[pkArg * kLot];
+                        ret_node = (int)e[pkRetNode * kLot];
+                        top = (int)e[pkTop * kLot];
+                        n_int = e[pkNInt * kLot];
+                        n_pts = e[pkNPts * kLot];
+                        ovf = e[pkOvf * kLot];
+                        st_d[0] = __uint_as_float(e[pkStD0 * kLot]);
+                        st_i[0] = e[pkStI0 * kLot];
+                        st_d[kWave] = __uint_as_float(e[pkStD1 * kLot]);
+                        st_i[kWave] = e[pkStI1 * kLot];
+                    }
+                    lot = 0;
+                    cur ^= 1u; // (what this batch parks again goes to the other lot)
+                }
+                else if (!valid)
                     mode = tDone;
                 else if (t.root < 0)
                 {
@@ -653,7 +810,7 @@ namespace icp_dev
                 // waves that step through nodes wait on memory most of the time: when one of them
                 // is ready it goes first, the scanning waves fill the issue slots in between
                 __builtin_amdgcn_s_setprio(1);
-                if (t.root >= 0)
+                if (t.root >= 0 && !flush)
                 {
                     for (;;)
                     {
@@ -721,6 +878,71 @@ namespace icp_dev
 
                 for (;;)
                 {
+                    // ---- stragglers leave for the lot (see the top of the kernel) ----
+                    if (park_on && !final_flush)
+                    {
+                        const bool at_work = mode <= tReturn;
+                        const uint64_t act = __ballot(at_work);
+                        const uint32_t na = (uint32_t)__builtin_popcountll(act);
+                        if (na != 0u && na <= park_max && low_rounds++ >= park_wait)
+                        {
+                            // a lane whose stack reaches into its HBM column stays (the column
+                            // belongs to the lane), and then so does the rest: the batch goes on
+                            // (the queries of a flush have their late rows already)
+                            const uint32_t need = flush ? 0u : na;
+                            const uint32_t late_rows = cold()->late_rows;
+                            if (__ballot(at_work && sp > (uint32_t)kStackK) == 0ull &&
+                                k_chunk + need <= late_rows)
+                            {
+                                if (at_work)
+                                {
+                                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi(
+                                        (uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+                                    uint32_t* e = lot_at(cur, lot + rank);
+                                    uint32_t i, late_row;
+                                    if (flush)
+                                    {
+                                        const uint32_t* from = lot_at(cur ^ 1u, (uint32_t)lane);
+                                        i = from[pkIndex * kLot];
+                                        late_row = from[pkRow * kLot];
+                                    }
+                                    else
+                                    {
+                                        i = b * batch_queries + (uint32_t)lane;
+                                        late_row = chunk * late_rows + k_chunk + rank;
+                                    }
+                                    e[pkQx * kLot] = __float_as_uint(qx);
+                                    e[pkQy * kLot] = __float_as_uint(qy);
+                                    e[pkQz * kLot] = __float_as_uint(qz);
+                                    e[pkNode * kLot] = (uint32_t)node;
+                                    e[pkPrev * kLot] = (uint32_t)prev;
+                                    e[pkModeSp * kLot] = (uint32_t)mode | (sp << 8);
+                                    e[pkRd * kLot] = __float_as_uint(rd);
+                                    e[pkRid * kLot] = rid;
+                                    e[pkChainM * kLot] = __float_as_uint(chain_m);
+                                    e[pkChainM2 * kLot] = __float_as_uint(chain_m2);
+                                    e[pkArg * kLot] = (uint32_t)arg;
+                                    e[pkRetNode * kLot] = (uint32_t)ret_node;
+                                    e[pkTop * kLot] = (uint32_t)top;
+                                    e[pkNInt * kLot] = n_int;
+                                    e[pkNPts * kLot] = n_pts;
+                                    e[pkOvf * kLot] = ovf;
+                                    e[pkIndex * kLot] = i;
+                                    e[pkRow * kLot] = late_row;
+                                    e[pkStD0 * kLot] = __float_as_uint(st_d[0]);
+                                    e[pkStI0 * kLot] = st_i[0];
+                                    e[pkStD1 * kLot] = __float_as_uint(st_d[kWave]);
+                                    e[pkStI1 * kLot] = st_i[kWave];
+                                    mode = tDone;
+                                    valid = false; // not this batch's to finish
+                                }
+                                lot += na;
+                                k_chunk += need;
+                                if (STATS)
+                                    st_tile_len += na; // (diagnostic build: lanes parked)
+                            }
+                        }
+                    }
                     // ---- node phase: step every lane until it waits on a bucket or is done ----
                     const unsigned long long cy_n0 = now();
                     __builtin_amdgcn_s_setprio(1);
@@ -1109,26 +1331,58 @@ namespace icp_dev
                         oy = N.cy;
                         oz = N.cz;
                     }
+                    // the query's index: its place in the batch, or what its lot entry says
+                    const uint32_t i = flush ? lot_at(cur ^ 1u, (uint32_t)lane)[pkIndex * kLot]
+                                             : b * batch_queries + (uint32_t)lane;
                     if (yx)
                     {
                         yx[i] = ox;
                         yy[i] = oy;
                         yz[i] = oz;
                     }
-                    if (row_out || dist_out)
+                    if (args.want_rows)
                     {
-                        const uint32_t o = perm ? perm[i] : i; // back to the caller's order
-                        if (row_out)
-                            row_out[o] = rid < t.n_slots ? t.srow[rid] : t.nrow[rid - t.n_slots];
-                        if (dist_out)
-                            dist_out[o] = rd;
+                        tile_args_ptr A = cold();
+                        const uint32_t o = A->perm ? A->perm[i] : i; // back to the caller's order
+                        if (A->row_out)
+                            A->row_out[o] = rid < t.n_slots ? A->t.srow[rid] : A->t.nrow[rid - t.n_slots];
+                        if (A->dist_out)
+                            A->dist_out[o] = rd;
                     }
                 }
                 // fp32 products as find_covariance forms them (point-3d.cc:220-231), summed in
                 // fp64 in a fixed order: twelve per-lane values -> (permlane32 swap) six registers
                 // of two 32-lane halves -> (permlane16 swap) three registers of four 16-lane rows
                 // -> row sums by DPP -> this wave's running totals in LDS.
+                if (flush)
                 {
+                    // a parked query's terms go to its own row (fp32 products, point-3d.cc:220-231)
+                    if (valid)
+                    {
+                        // (word by word: built as 16-byte vectors the three counters became
+                        // one register tuple for the whole kernel, and that tuple spilled)
+                        const uint32_t late_row = lot_at(cur ^ 1u, (uint32_t)lane)[pkRow * kLot];
+                        uint32_t* row = cold()->late + (size_t)late_row * kCovSums;
+                        row[0] = __float_as_uint(__fmul_rn(qx, ox));
+                        row[1] = __float_as_uint(__fmul_rn(qx, oy));
+                        row[2] = __float_as_uint(__fmul_rn(qx, oz));
+                        row[3] = __float_as_uint(__fmul_rn(qy, ox));
+                        row[4] = __float_as_uint(__fmul_rn(qy, oy));
+                        row[5] = __float_as_uint(__fmul_rn(qy, oz));
+                        row[6] = __float_as_uint(__fmul_rn(qz, ox));
+                        row[7] = __float_as_uint(__fmul_rn(qz, oy));
+                        row[8] = __float_as_uint(__fmul_rn(qz, oz));
+                        row[9] = n_int;
+                        row[10] = n_pts;
+                        row[11] = ovf;
+                    }
+                }
+                else
+                {
+                    // (a lane parked by this batch adds nothing here: ox = oy = oz = 0 and its
+                    // counters travel with it)
+                    if (!valid)
+                        n_int = n_pts = ovf = 0u;
                     double v[kCovSums];
                     v[0] = (double)__fmul_rn(qx, ox);
                     v[1] = (double)__fmul_rn(qx, oy);
@@ -1176,9 +1430,9 @@ namespace icp_dev
                     atomicAdd(cls + 7, (unsigned long long)(st_tile - st_tile_b0));
                     atomicAdd(cls + 8, (unsigned long long)(st_coop - st_coop_b0));
                 }
+                if (!flush)
+                    b += 1u;
             }
-                if (chunk_sums && lane_c < (uint32_t)kCovSums)
-                    chunk_sums[(size_t)chunk * kCovSums + lane_c] = L.sums[lane_c];
             }
             // (diagnostic build: this wave's end, before the counters below queue up on their words)
             const unsigned long long rt_end = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -1187,6 +1441,7 @@ namespace icp_dev
             __syncthreads();
             if (threadIdx.x == 0)
             {
+                uint32_t* queue = cold()->queue;
                 const uint32_t finished = __hip_atomic_fetch_add(queue + 256, 1u, __ATOMIC_RELAXED,
                                                                  __HIP_MEMORY_SCOPE_AGENT);
                 if (finished == gridDim.x - 1u)
@@ -1369,21 +1624,49 @@ namespace icp_dev
             return hipErrorInvalidValue;
         if (a.height > (uint32_t)kStackK && !q.spill)
             return hipErrorInvalidValue;
+        if (q.park && (q.park_max == 0 || q.park_max > kParkMaxLanes || !q.late || !q.late_cnt ||
+                       q.late_rows == 0))
+            return hipErrorInvalidValue;
         const uint32_t bq = q.batch_queries;
         if (bq != 64u && bq != 32u && bq != 16u && bq != 8u && bq != 4u && bq != 2u)
             return hipErrorInvalidValue;
         const uint32_t n_batches = (a.n + bq - 1) / bq;
         const uint32_t n_chunks = (n_batches + q.chunk_batches - 1) / q.chunk_batches;
+        TileArgs k{};
+        k.t = a.tree;
+        k.px = a.px;
+        k.py = a.py;
+        k.pz = a.pz;
+        k.mux = a.mu[0];
+        k.muy = a.mu[1];
+        k.muz = a.mu[2];
+        k.n = a.n;
+        k.yx = a.yx;
+        k.yy = a.yy;
+        k.yz = a.yz;
+        k.cut = q.cut;
+        k.batch_queries = bq;
+        k.park_max = q.park ? (q.park_max | (q.park_wait << 8)) : 0u;
+        k.want_rows = (a.row_out || a.dist_out) ? 1u : 0u;
+        k.row_out = a.row_out;
+        k.dist_out = a.dist_out;
+        k.perm = a.perm;
+        k.chunk_sums = q.chunk_sums;
+        k.queue = q.queue;
+        k.spill = q.spill;
+        k.n_batches = n_batches;
+        k.chunk_batches = q.chunk_batches;
+        k.n_chunks = n_chunks;
+        k.late_rows = q.late_rows;
+        k.park = q.park;
+        k.late = q.late;
+        k.late_cnt = q.late_cnt;
+        k.stats = q.stats;
+        k.loop = a.loop;
         if (q.stats)
-            hipLaunchKernelGGL(nn_tile_kernel<true>, dim3(a.grid), dim3(kBlock), 0, s, a.tree, a.px,
-                               a.py, a.pz, a.mu[0], a.mu[1], a.mu[2], a.n, a.yx, a.yy, a.yz,
-                               a.row_out, a.dist_out, a.perm, q.chunk_sums, q.queue, q.spill,
-                               n_batches, q.chunk_batches, n_chunks, q.cut, bq, q.stats, a.loop);
+            hipLaunchKernelGGL(nn_tile_kernel<true>, dim3(a.grid), dim3(kBlock), 0, s, k);
         else
-            hipLaunchKernelGGL(nn_tile_kernel<false>, dim3(a.grid), dim3(kBlock), 0, s, a.tree, a.px,
-                               a.py, a.pz, a.mu[0], a.mu[1], a.mu[2], a.n, a.yx, a.yy, a.yz,
-                               a.row_out, a.dist_out, a.perm, q.chunk_sums, q.queue, q.spill,
-                               n_batches, q.chunk_batches, n_chunks, q.cut, bq, nullptr, a.loop);
+            hipLaunchKernelGGL(nn_tile_kernel<false>, dim3(a.grid), dim3(kBlock), 0, s, k);
         return hipGetLastError();
     }
 } // namespace icp_dev
