@@ -243,6 +243,9 @@ namespace
     };
 } // namespace
 
+constexpr uint64_t kParkMinPoints = 6'000'000;       // shards from which the straggler lots pay once aligned
+constexpr uint64_t kParkMinPointsEarly = 40'000'000; // ... and while the clouds are still apart
+
 struct icp_hip_ctx
 {
     int device = 0;
@@ -312,17 +315,29 @@ struct icp_hip_ctx
     // When: measured on one MI355X (scripts/park_probe.py, bench.py): once the clouds are aligned
     // the pass is 9-13 % faster from 16M points up, 3 % at 8M, and SLOWER below (every wave ends
     // with a batch of what is left in its lot, which weighs on a short pass); while the clouds
-    // are still a point spacing apart it is 5 % faster at 64M points and 9 % slower at 16M.  So
-    // the lots are used on shards of kParkMinPoints and more, in the passes after the second
-    // ordering pass (maybe_resort: the registration's own sign that the clouds are aligned).
-    // ICP_HIP_PARK=always / never overrides (tests, experiments).
-    uint32_t park_max = 8;        // ICP_HIP_PARK_MAX
+    // are still a point spacing apart it is 5 % faster at 64M points, even at 32M and 9 % slower
+    // at 16M (best there with up to 16 lanes parked per batch, 8 late rows per batch; aligned: 8
+    // and 2).  So the lots are used on shards of kParkMinPoints and more in the passes after the
+    // second ordering pass (maybe_resort: the registration's own sign that the clouds are
+    // aligned), and from kParkMinPointsEarly in the passes before it.
+    // ICP_HIP_PARK=always / never and ICP_HIP_PARK_MAX / ICP_HIP_LATE_PER_BATCH override (tests,
+    // experiments).
+    uint32_t park_max_env = 0, late_per_batch_env = 0; // 0: not set
     uint32_t park_wait = 0;       // ICP_HIP_PARK_WAIT
-    uint32_t late_per_batch = 2;  // ICP_HIP_LATE_PER_BATCH: late rows of a chunk = this x its batches
     int park_mode = 0;            // 0: the rule above, 1: always, 2: never
     bool park_ready = false;      // lots and late rows are allocated for the current launch shape
-    bool park_now() const { return park_ready && (park_mode == 1 || resorted); }
-    uint32_t late_rows() const { return late_per_batch * chunk_batches; }
+    bool park_now() const
+    {
+        return park_ready && (park_mode == 1 || resorted || n_local >= kParkMinPointsEarly);
+    }
+    uint32_t park_max() const { return park_max_env ? park_max_env : resorted ? 8u : 16u; }
+    uint32_t late_per_batch() const { return late_per_batch_env ? late_per_batch_env : resorted ? 2u : 8u; }
+    uint32_t late_per_batch_most() const
+    {
+        return late_per_batch_env ? late_per_batch_env
+                                  : (park_mode == 1 || n_local >= kParkMinPointsEarly) ? 8u : 2u;
+    }
+    uint32_t late_rows() const { return late_per_batch() * chunk_batches; }
 
     icp_hip_allreduce_fn allreduce = nullptr;
     void* allreduce_user = nullptr;
@@ -445,7 +460,6 @@ namespace
         return a;
     }
 
-    constexpr uint64_t kParkMinPoints = 6'000'000; // shards from which the straggler lots pay
 
     // Size the tile kernel's launch for the current tree + shard (called when either changes;
     // allocates, so never from the iteration loop).
@@ -486,14 +500,14 @@ namespace
         }
         // (a small shard runs a handful of batches: nothing to gather in a lot)
         c->park_ready = false;
-        if (!c->small && c->park_max != 0 && c->batch_queries == 64 && c->park_mode != 2 &&
+        if (!c->small && c->batch_queries == 64 && c->park_mode != 2 &&
             (c->park_mode == 1 || c->n_local >= kParkMinPoints))
         {
             HIP_TRY(c, c->park.alloc((size_t)c->tile_grid_blocks * 4 * 2 * kParkLotWords));
             // late rows: late_per_batch per batch however the batches are cut into chunks
             // (maybe_resort makes the chunks larger later; a last partial chunk rounds up)
             const uint64_t batches = (c->n_local + c->batch_queries - 1) / c->batch_queries;
-            HIP_TRY(c, c->late.alloc((size_t)(batches + 64) * c->late_per_batch * kCovSums));
+            HIP_TRY(c, c->late.alloc((size_t)(batches + 64) * c->late_per_batch_most() * kCovSums));
             HIP_TRY(c, c->late_cnt.alloc(c->n_chunks));
             c->park_ready = true;
         }
@@ -551,7 +565,7 @@ namespace
             q.late = c->late.p;
             q.late_cnt = c->late_cnt.p;
             q.late_rows = c->late_rows();
-            q.park_max = c->park_max;
+            q.park_max = c->park_max();
             q.park_wait = c->park_wait;
         }
         if (q.stats)
@@ -1711,11 +1725,11 @@ extern "C"
                 c->park_mode = std::strcmp(pk, "always") == 0 ? 1
                                : (std::strcmp(pk, "never") == 0 || std::strcmp(pk, "0") == 0) ? 2 : 0;
             if (const char* pm = std::getenv("ICP_HIP_PARK_MAX"))
-                c->park_max = std::min((uint32_t)std::max(0, std::atoi(pm)), kParkMaxLanes);
+                c->park_max_env = std::min((uint32_t)std::max(0, std::atoi(pm)), kParkMaxLanes);
             if (const char* pw = std::getenv("ICP_HIP_PARK_WAIT"))
                 c->park_wait = std::min((uint32_t)std::max(0, std::atoi(pw)), 255u);
             if (const char* lb = std::getenv("ICP_HIP_LATE_PER_BATCH"))
-                c->late_per_batch = std::min((uint32_t)std::max(1, std::atoi(lb)), 32u);
+                c->late_per_batch_env = std::min((uint32_t)std::max(1, std::atoi(lb)), 32u);
         }
         *out = c;
         return ICP_HIP_OK;

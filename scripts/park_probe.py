@@ -16,6 +16,7 @@ p1 = synth.apply_fp32(p0, synth.expected_transform(ang).astype(np.float32))
 for s in settings:
     pm, lpb, cb, *pw = s.split(":")
     os.environ["ICP_HIP_PARK_WAIT"] = pw[0] if pw else "0"
+    os.environ["ICP_HIP_PARK"] = "never" if pm == "0" else "always"
     os.environ["ICP_HIP_PARK_MAX"] = pm
     os.environ["ICP_HIP_LATE_PER_BATCH"] = lpb
     if int(cb):
