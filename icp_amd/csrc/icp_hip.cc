@@ -297,6 +297,10 @@ struct icp_hip_ctx
     double* h_sums = nullptr; // pinned, 16 doubles
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // icp_hip_nn_noalloc runs on the CALLER's stream and reads this context's tree: the event is
+    // recorded behind every such launch and waited for before a tree block is released
+    hipEvent_t noalloc_ev = nullptr;
+    bool noalloc_pending = false;
     uint32_t tile_blocks = 0;   // resident nn_tile_kernel workgroups on this device (multiple of 8)
     uint32_t cus = 0;           // compute units (0 when tile_blocks is not a whole number per CU)
     bool force_deep = false;    // ICP_HIP_NN_KERNEL=deep: always run nn_cov_kernel
@@ -433,6 +437,15 @@ namespace
         if (c->allreduce && c->allreduce(c->h_sums + first, count, c->allreduce_user) != 0)
             return fail(c, ICP_HIP_ERR_COMM, "all-reduce callback failed");
         return ICP_HIP_OK;
+    }
+
+    // Before a tree block is released (replaced tree, destroyed context): the last
+    // icp_hip_nn_noalloc launch, which reads the tree from a stream that is not the context's.
+    void drain_noalloc(icp_hip_ctx* c)
+    {
+        if (c->noalloc_pending && c->noalloc_ev)
+            (void)hipEventSynchronize(c->noalloc_ev);
+        c->noalloc_pending = false;
     }
 
     NnLaunch make_nn(icp_hip_ctx* c, const float mu[3], bool want_y, bool want_row, bool want_dist,
@@ -952,6 +965,7 @@ namespace
                         "icp_hip_set_tree: tree height " + std::to_string(t->height) +
                             " exceeds the traversal stack (" +
                             std::to_string(nn_max_depth_supported()) + " levels)");
+        drain_noalloc(c);
         if (c->has_tree) // a replaced tree's blocks go back to the pool: nothing may still use them
             HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->has_tree = false;
@@ -1701,6 +1715,8 @@ extern "C"
             if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount,
                                            device_id)) != hipSuccess)
                 return bail(e, "hipDeviceGetAttribute");
+            if ((e = hipEventCreateWithFlags(&c->noalloc_ev, hipEventDisableTiming)) != hipSuccess)
+                return bail(e, "hipEventCreate");
             // the static scratch array of icp_hip_nn_noalloc: its address on this device
             if ((e = nn_noalloc_setup(device_id)) != hipSuccess)
                 return bail(e, "hipGetSymbolAddress(scratch)");
@@ -1742,6 +1758,10 @@ extern "C"
         DeviceGuard g(c->device);
         if (c->stream)
             (void)hipStreamSynchronize(c->stream);
+        drain_noalloc(c);
+        if (c->noalloc_ev)
+            (void)hipEventDestroy(c->noalloc_ev);
+        c->noalloc_ev = nullptr;
         if (c->comm && g_rccl.CommDestroy)
             (void)g_rccl.CommDestroy(c->comm);
         c->nodes.release();
@@ -1838,6 +1858,7 @@ extern "C"
                         "icp_hip_build_tree: capacity <= 2 is undefined behaviour in the reference "
                         "(vp-tree.cc:114: empty inside set on 2-point nodes)");
         DeviceGuard g(c->device);
+        drain_noalloc(c);
         c->has_tree = false;
         // A small cloud is built by the host builder (same tree, bit for bit) and uploaded: the
         // level-by-level device build costs ~0.1 ms of launches per level whatever the size.
@@ -2188,6 +2209,14 @@ extern "C"
             return fail(c, ICP_HIP_ERR_ARG, "icp_hip_nn_noalloc: NULL argument");
         if (!c->has_tree)
             return fail(c, ICP_HIP_ERR_ARG, "icp_hip_nn_noalloc: the context has no tree");
+        if (stream)
+        {
+            int sdev = -1;
+            if (hipStreamGetDevice((hipStream_t)stream, &sdev) == hipSuccess && sdev != c->device)
+                return fail(c, ICP_HIP_ERR_ARG,
+                            "icp_hip_nn_noalloc: the stream belongs to device " + std::to_string(sdev) +
+                                ", the context to device " + std::to_string(c->device));
+        }
         if ((d_yx || d_yy || d_yz) && !(d_yx && d_yy && d_yz))
             return fail(c, ICP_HIP_ERR_ARG, "icp_hip_nn_noalloc: d_yx, d_yy, d_yz go together");
         if (n == 0)
@@ -2221,6 +2250,9 @@ extern "C"
         a.row_out = d_row_out;
         a.dist_out = d_dist_out;
         HIP_TRY(c, launch_nn_noalloc(c->device, a, d_sums_out, c->tile_cut, (hipStream_t)stream));
+        // (recording an event allocates nothing; the event itself was made by icp_hip_create)
+        HIP_TRY(c, hipEventRecord(c->noalloc_ev, (hipStream_t)stream));
+        c->noalloc_pending = true;
         return ICP_HIP_OK;
     }
 

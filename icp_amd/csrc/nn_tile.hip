@@ -1437,7 +1437,21 @@ namespace icp_dev
             // (diagnostic build: this wave's end, before the counters below queue up on their words)
             const unsigned long long rt_end = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
             cy_total = now() - cy_begin;
-            // the last workgroup to get here leaves the queue heads zero for the next launch
+            // the last workgroup to get here leaves the queue heads zero for the next launch.
+            // Why relaxed atomics are enough (nothing but the queue words is ordered by them):
+            //  * every access to the heads and to the count is an agent-scope atomic on one
+            //    word, and atomics on one word are totally ordered (coherence), whatever their
+            //    memory order;
+            //  * a wave's last fetch_add on a head RETURNED before the wave left the loop above
+            //    (the loop's exit depends on the value), all four waves pass the barrier below
+            //    after that, and only then does thread 0 take its ticket: the ticket of a
+            //    workgroup follows every head access of that workgroup in program order, and a
+            //    returned atomic has been performed at L2;
+            //  * so when a workgroup draws the last ticket, every head access of every
+            //    workgroup has been performed, and its stores are the last writes to those
+            //    words in this launch; the next launch on the stream starts after this one has
+            //    ended, which makes them visible to it.
+            // (The sums and outputs need no ordering here: nobody in this launch reads them.)
             __syncthreads();
             if (threadIdx.x == 0)
             {

@@ -17,8 +17,8 @@
  *   - plain pointers and sizes only; caller-owned buffers stay caller-owned; a context owns its
  *     device memory, its HIP stream and (optionally) its RCCL communicator;
  *   - one context drives ONE GPU and must not be used from two threads at once; multi-GPU runs
- *     are one process (or thread) per GPU, each with its own context holding a contiguous shard
- *     of the query cloud and a full replica of the tree;
+ *     are one process (or thread) per GPU, each with its own context holding a shard of the
+ *     query cloud (any subset of its rows: see icp_hip_set_queries) and a full replica of the tree;
  *   - points are the reference's Point3D layout: 3 packed floats x,y,z (libcpu/point-3d.hh:12-17);
  *   - the 4x4 transform is row-major, values[i*4+j] (libcpu/utils/matrix.hh:149).
  */
@@ -199,9 +199,14 @@ int icp_hip_nn(icp_hip_ctx* ctx, const float mu_p[3], uint32_t* row_out, float* 
  *   - the call makes no hipMalloc / hipFree / allocating library call: the kernel's work queue,
  *     per-chunk sums and overflow stack live in a static device array of 17.4 MB that every GPU
  *     the library runs on holds until the process ends.  Hence the limits: n <= 1,048,576
- *     queries per call (ICP_HIP_ERR_ARG beyond) and tree height <= 32 (ICP_HIP_ERR_DEPTH), and a
+ *     queries per call (ICP_HIP_ERR_ARG beyond) and tree height <= 32 (ICP_HIP_ERR_DEPTH: 2 on-chip stack entries + 30 in the array), and a
  *     grid of one workgroup per CU.  All calls on one GPU share that array: calls that overlap
- *     on one GPU (two streams, two contexts, two threads) race; serialise them. */
+ *     on one GPU (two streams, two contexts, two threads) race; serialise them;
+ *   - the kernel reads the context's tree from the CALLER's stream.  The library waits for the
+ *     last such launch (an event recorded behind it) before it releases a tree block
+ *     (icp_hip_set_tree / icp_hip_build_tree replacing the tree, icp_hip_destroy), so those
+ *     calls block until the caller's stream has got that far; `stream` must belong to the
+ *     context's device (ICP_HIP_ERR_ARG otherwise). */
 int icp_hip_nn_noalloc(icp_hip_ctx* ctx, const float* d_px, const float* d_py, const float* d_pz,
                        uint32_t n, const float mu_p[3], uint32_t* d_row_out, float* d_dist_out,
                        float* d_yx, float* d_yy, float* d_yz, double* d_sums_out, void* stream);
@@ -289,7 +294,7 @@ typedef struct icp_hip_timing {
     double nodes_visited;
     double points_scanned;
     double stack_spills; /* traversal-stack entries that left LDS for HBM (far-side nesting
-                            deeper than the kernel's 4 on-chip entries); diagnostic */
+                            deeper than the kernel's 2 on-chip entries); diagnostic */
 } icp_hip_timing;
 int icp_hip_get_timing(icp_hip_ctx* ctx, icp_hip_timing* out);
 /* NN-kernel milliseconds of each iteration of the last icp_hip_run (first `capacity` entries

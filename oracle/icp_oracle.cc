@@ -7,7 +7,7 @@
 //
 // Parity pin: every function below except the 3x3 SVD is checked bit-for-bit against the
 // reference's own libcpu sources compiled unmodified into oracle/_ref (see oracle/Makefile,
-// oracle/ref_driver.cc, tests/test_oracle_vs_ref.py) and against the committed golden
+// oracle/ref_driver.cc, tests/test_oracle.py) and against the committed golden
 // fixtures generated from that build (tests/golden/).  The SVD step is Eigen 3.3.7
 // JacobiSVD<Matrix3f> (third-party, fetched by URL in the reference's CMakeLists.txt:27-30,
 // absent offline): its 2x2-Jacobi algorithm is restated from its published description and
