@@ -57,6 +57,12 @@ def parse(argv=None):
                     help="queries of the CPU-baseline sample (0 disables the baseline)")
     ap.add_argument("--cpu-repeats", type=int, default=0,
                     help="CPU-baseline repeats (default: 5 at <= 4M points, 3 above; median taken)")
+    ap.add_argument("--partition", default="spatial", choices=["spatial", "rows-exchange"],
+                    help="N > 1: how a rank gets its shard.  spatial: the caller cuts the cloud "
+                         "into compact parts itself (icp_amd.dist.spatial_shard, host numpy).  "
+                         "rows-exchange: every rank hands over a contiguous slice of the (randomly "
+                         "ordered) rows and the library re-partitions behind the ABI "
+                         "(icp_hip_set_queries_exchange)")
     ap.add_argument("--allow-fallback", action="store_true",
                     help="N > 1: if the RCCL communicator does not come up on every rank, let all "
                          "ranks fall back to the host-callback all-reduce instead of exiting non-zero")
@@ -234,11 +240,18 @@ def main():
         # share of the one-GPU pass).  A caller partitions a scan by position; so does the bench
         # (icp_amd.dist.spatial_shard: median planes, equal sizes, the same partition on every
         # rank).  Set-up, like the tree build: outside the timed region.
-        rows = spatial_shard(m[:n_queries_total], world, rank)
-        begin, end = 0, len(rows)
-        p_shard = synth.apply_fp32(m[rows], gt)
-        shards = "spatially compact parts of equal size (median planes, icp_amd.dist.spatial_shard)"
-        del rows
+        if args.partition == "spatial":
+            rows = spatial_shard(m[:n_queries_total], world, rank)
+            begin, end = 0, len(rows)
+            p_shard = synth.apply_fp32(m[rows], gt)
+            shards = "spatially compact parts of equal size (median planes, icp_amd.dist.spatial_shard)"
+            del rows
+        else:
+            from icp_amd.dist import shard_bounds
+            begin, end = shard_bounds(n_queries_total, world, rank)
+            p_shard = synth.apply_fp32(m[begin:end], gt)
+            shards = ("contiguous slices of the randomly ordered rows, re-partitioned behind the ABI "
+                      "into compact regions (icp_hip_set_queries_exchange)")
     t_gen = time.time() - t0
 
     t0 = time.time()
@@ -293,6 +306,7 @@ def main():
         from icp_amd.dist import torch_allreduce
         ctx.set_allreduce(torch_allreduce())
         allreduce_path = "REHEARSAL on one shared GPU: gloo all-reduce from the host loop"
+    ctx_uses_callback = share_gpu_cb or allreduce_path.startswith("FALLBACK")
     ctx.build_tree(mc[:4096], args.capacity)   # first-call costs (code load) out of the timing
     t0 = time.time()
     ctx.build_tree(mc, args.capacity)
@@ -317,10 +331,22 @@ def main():
         torch.cuda.empty_cache()
 
     # ---------------- warm-up ----------------
-    ctx.set_queries(p_shard, n_total=n_queries_total)
+    def upload():
+        if world > 1 and args.partition == "rows-exchange":
+            ctx.set_queries_exchange(p_shard, n_total=n_queries_total)
+        else:
+            ctx.set_queries(p_shard, n_total=n_queries_total)
+    if world > 1 and args.partition == "rows-exchange" and ctx_uses_callback:
+        # (host-callback runs move the points over the process group too; an RCCL communicator
+        # moves them itself, ncclSend / ncclRecv)
+        from icp_amd.dist import torch_alltoallv
+        ctx.set_alltoallv(world, rank, torch_alltoallv(
+            device=None if share_gpu else torch.device("cuda", local_rank)))
+    upload()
     if args.warmup > 0:
         ctx.run(mu_m, args.warmup, 0.0)
-    ctx.set_queries(p_shard, n_total=n_queries_total)  # back to the initial clouds; resets timers
+    upload()  # back to the initial clouds; resets timers
+    shard_points = ctx.shard_size()[0]
 
     # ---------------- timed region: exactly K iterations ----------------
     barrier_sync()
@@ -362,7 +388,7 @@ def main():
     bytes_per_launch = alg_bytes_all / launches / world       # one GPU's launch (mean over ranks)
     avg_ms = tm["nn_ms"] / launches
     avg_s = avg_ms * 1e-3
-    n_gpu = float(end - begin)
+    n_gpu = float(shard_points)
     cpath = os.path.join("profiles", f"nn_counters_{args.workload}.json")
     counters = load_counters(args, n_m, n_queries_total)
     tree_bytes = 12.0 * tinfo["n_slots"] + 32.0 * tinfo["n_nodes"]
@@ -416,7 +442,7 @@ def main():
                             f"steps, capacity, angle, queries): frac / traffic are null")
 
     # ---------------- per-rank record (N > 1: gathered after the timed region) ----------------
-    mine = {"rank": rank, "queries": int(end - begin), "wall_ms_per_step": round(my_dt / args.steps * 1e3, 4),
+    mine = {"rank": rank, "queries": int(shard_points), "wall_ms_per_step": round(my_dt / args.steps * 1e3, 4),
             "nn_ms_per_step": round(tm["nn_ms"] / launches, 4),
             "apply_ms_per_step": round(tm["apply_ms"] / launches, 4),
             "nn_ms_first_iter": round(float(trace[0]), 4) if len(trace) else None,

@@ -25,7 +25,8 @@ EXPORTS = [
     "icp_hip_set_queries", "icp_hip_nn", "icp_hip_nn_noalloc",
     "icp_hip_set_allreduce", "icp_hip_comm_unique_id", "icp_hip_comm_init_rank", "icp_hip_run",
     "icp_hip_get_points", "icp_hip_get_timing", "icp_hip_get_nn_trace", "icp_hip_icp",
-    "icp_hip_set_phase_timers",
+    "icp_hip_set_phase_timers", "icp_hip_set_queries_exchange", "icp_hip_set_alltoallv",
+    "icp_hip_get_shard_size",
 ]
 
 
@@ -59,6 +60,8 @@ class TimingStruct(C.Structure):
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int, C.c_void_p)
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_uint64, C.c_uint64, C.c_float, C.c_void_p)
+ALLTOALLV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p,
+                           C.POINTER(C.c_uint64), C.c_int, C.c_void_p)
 
 _lib = None
 
@@ -101,6 +104,9 @@ def load() -> C.CDLL:
     L.icp_hip_get_tree.argtypes = [vp, C.POINTER(treep)]
     L.icp_hip_get_tree_info.argtypes = [vp, treep]
     L.icp_hip_set_queries.argtypes = [vp, vp, u64, u64]
+    L.icp_hip_set_queries_exchange.argtypes = [vp, vp, u64, u64]
+    L.icp_hip_set_alltoallv.argtypes = [vp, C.c_int, C.c_int, ALLTOALLV_FN, vp]
+    L.icp_hip_get_shard_size.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     L.icp_hip_nn.argtypes = [vp, vp, vp, vp, vp, C.POINTER(C.c_float)]
     L.icp_hip_nn_noalloc.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.icp_hip_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp]
@@ -283,6 +289,44 @@ class Context:
         _check(self._L.icp_hip_set_queries(self._h, a.ctypes.data, len(a),
                                            int(n_total if n_total is not None else len(a))),
                self._h)
+
+    def set_alltoallv(self, n_ranks: int, rank: int, fn):
+        """fn(send: bytes-like uint8 array, send_bytes: list[int], recv_bytes: list[int]) ->
+        uint8 array of sum(recv_bytes) bytes: the blocks from ranks 0 .. n_ranks-1 back to back."""
+        if fn is None:
+            cb = C.cast(None, ALLTOALLV_FN)
+        else:
+            def _cb(send, send_bytes, recv, recv_bytes, n, _user):
+                try:
+                    sb = [int(send_bytes[r]) for r in range(n)]
+                    rb = [int(recv_bytes[r]) for r in range(n)]
+                    src = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(max(1, sum(sb)),))
+                    out = np.asarray(fn(src[:sum(sb)], sb, rb), np.uint8)
+                    assert out.size == sum(rb)
+                    if out.size:
+                        C.memmove(recv, out.ctypes.data, out.size)
+                    return 0
+                except Exception:  # never let an exception cross the C ABI
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            cb = ALLTOALLV_FN(_cb)
+        self._keep.append(cb)
+        _check(self._L.icp_hip_set_alltoallv(self._h, int(n_ranks), int(rank), cb, None), self._h)
+
+    def set_queries_exchange(self, xyz, n_total: int):
+        """icp_hip_set_queries_exchange: collective; this rank hands over ITS rows, registers the
+        points of its region of the tree, and get_points() (collective too) returns its rows."""
+        a = _pts(xyz)
+        _check(self._L.icp_hip_set_queries_exchange(self._h, a.ctypes.data, len(a), int(n_total)), self._h)
+        self.n_local = len(a)          # what get_points() returns
+        self._exchanged = True
+
+    def shard_size(self) -> tuple[int, int]:
+        """(points this context registers, points of the whole cloud)."""
+        a, b = C.c_uint64(), C.c_uint64()
+        _check(self._L.icp_hip_get_shard_size(self._h, C.byref(a), C.byref(b)), self._h)
+        return a.value, b.value
 
     def nn(self, mu_p, want=("row", "xyz", "dist")):
         """One NN pass; returns dict with the requested host arrays + kernel_ms."""

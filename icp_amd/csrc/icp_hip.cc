@@ -41,12 +41,17 @@ namespace
         int (*GetUniqueId)(UniqueId*) = nullptr;
         int (*CommInitRank)(Comm*, int, UniqueId, int) = nullptr;
         int (*AllReduce)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+        int (*Send)(const void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+        int (*Recv)(void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+        int (*GroupStart)() = nullptr;
+        int (*GroupEnd)() = nullptr;
         int (*CommDestroy)(Comm) = nullptr;
         const char* (*GetErrorString)(int) = nullptr;
         void* handle = nullptr;
         bool tried = false;
         static constexpr int kDouble = 8; // ncclDouble / ncclFloat64
         static constexpr int kSum = 0;    // ncclSum
+        static constexpr int kInt8 = 0;   // ncclInt8 / ncclChar
 
         bool load(std::string& err)
         {
@@ -74,6 +79,10 @@ namespace
             AllReduce = (decltype(AllReduce))dlsym(handle, "ncclAllReduce");
             CommDestroy = (decltype(CommDestroy))dlsym(handle, "ncclCommDestroy");
             GetErrorString = (decltype(GetErrorString))dlsym(handle, "ncclGetErrorString");
+            Send = (decltype(Send))dlsym(handle, "ncclSend");
+            Recv = (decltype(Recv))dlsym(handle, "ncclRecv");
+            GroupStart = (decltype(GroupStart))dlsym(handle, "ncclGroupStart");
+            GroupEnd = (decltype(GroupEnd))dlsym(handle, "ncclGroupEnd");
             if (!GetUniqueId || !CommInitRank || !AllReduce || !CommDestroy)
             {
                 err = "librccl is missing ncclGetUniqueId/ncclCommInitRank/ncclAllReduce";
@@ -346,7 +355,17 @@ struct icp_hip_ctx
     icp_hip_allreduce_fn allreduce = nullptr;
     void* allreduce_user = nullptr;
     Rccl::Comm comm = nullptr;
-    int n_ranks = 1;
+    int n_ranks = 1, rank = 0; // of the RCCL communicator
+
+    // icp_hip_set_queries_exchange: the caller's rows went to the ranks that own their region of
+    // the tree; what is needed to bring the moved points back to the caller's rows
+    icp_hip_alltoallv_fn alltoallv = nullptr;
+    void* alltoallv_user = nullptr;
+    int ex_ranks = 0, ex_rank = 0;          // of the callback (icp_hip_set_alltoallv)
+    bool exchanged = false;                 // the shard in HBM is not the caller's rows
+    uint64_t ex_n_caller = 0;               // rows the caller handed over
+    std::vector<uint64_t> ex_sent, ex_got;  // points sent to / received from each rank
+    std::vector<uint32_t> ex_rows;          // caller's row of every point sent, in send order
 
     icp_hip_timing timing{};
     std::vector<float> nn_trace; // NN kernel ms of each iteration of the last icp_hip_run
@@ -1521,6 +1540,136 @@ namespace
                 .count();
         return ICP_HIP_OK;
     }
+    // The shard as it stands in HBM, in the order it was handed to icp_hip_set_queries.
+    int get_points_local(icp_hip_ctx* c, float* xyz_aos)
+    {
+        if (c->n_local == 0)
+            return ICP_HIP_OK;
+        if (!xyz_aos)
+            return fail(c, ICP_HIP_ERR_ARG, "icp_hip_get_points: xyz_aos is NULL");
+        DeviceGuard g(c->device);
+        const uint32_t n = (uint32_t)c->n_local;
+        if (c->small && c->host_points_valid)
+        {
+            // the last registration brought the block back with its state: nothing to wait for
+            const float* hx = reinterpret_cast<const float*>(c->h_down + kSmallHead);
+            const float *hy = hx + c->small_pad, *hz = hy + c->small_pad;
+            for (uint32_t i = 0; i < n; ++i)
+            {
+                xyz_aos[3 * (size_t)i] = hx[i];
+                xyz_aos[3 * (size_t)i + 1] = hy[i];
+                xyz_aos[3 * (size_t)i + 2] = hz[i];
+            }
+            return ICP_HIP_OK;
+        }
+        {
+            int rc = flush_queries(c);
+            if (rc != ICP_HIP_OK)
+                return rc;
+        }
+        HIP_TRY(c, c->aos.alloc(3ull * n));
+        if (c->sorted)
+            HIP_TRY(c, launch_scatter_aos(c->px.p, c->py.p, c->pz.p, c->perm.p, n, c->aos.p,
+                                          c->stream));
+        else
+            HIP_TRY(c, launch_soa_to_aos(c->px.p, c->py.p, c->pz.p, n, c->aos.p, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(xyz_aos, c->aos.p, 3ull * n * sizeof(float),
+                                  hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return ICP_HIP_OK;
+    }
+
+    // ---- icp_hip_set_queries_exchange: a rank that cannot choose its rows ----
+    // One all-to-all of variable-size blocks between the ranks, through the caller's callback
+    // or, with an RCCL communicator, ncclSend / ncclRecv on staging buffers in HBM.  send / recv
+    // hold the blocks for / from ranks 0 .. R-1 back to back.
+    int exchange_blocks(icp_hip_ctx* c, const void* send, const uint64_t* send_bytes, void* recv,
+                        const uint64_t* recv_bytes, int R)
+    {
+        if (c->alltoallv)
+        {
+            if (c->alltoallv(send, send_bytes, recv, recv_bytes, R, c->alltoallv_user) != 0)
+                return fail(c, ICP_HIP_ERR_COMM, "all-to-all callback failed");
+            return ICP_HIP_OK;
+        }
+        if (!c->comm || !g_rccl.Send || !g_rccl.Recv || !g_rccl.GroupStart || !g_rccl.GroupEnd)
+            return fail(c, ICP_HIP_ERR_COMM,
+                        "icp_hip_set_queries_exchange: neither an all-to-all callback "
+                        "(icp_hip_set_alltoallv) nor an RCCL communicator with ncclSend / ncclRecv");
+        uint64_t ns = 0, nr = 0;
+        for (int r = 0; r < R; ++r)
+        {
+            ns += send_bytes[r];
+            nr += recv_bytes[r];
+        }
+        DevBuf<unsigned char> ds, dr;
+        HIP_TRY(c, ds.alloc(ns ? ns : 1));
+        HIP_TRY(c, dr.alloc(nr ? nr : 1));
+        int rc = ICP_HIP_OK;
+        hipError_t e = ns ? hipMemcpyAsync(ds.p, send, ns, hipMemcpyHostToDevice, c->stream) : hipSuccess;
+        int nrc = 0;
+        if (e == hipSuccess)
+        {
+            nrc = g_rccl.GroupStart();
+            uint64_t so = 0, ro = 0;
+            for (int r = 0; r < R && nrc == 0; ++r)
+            {
+                if (send_bytes[r])
+                    nrc = g_rccl.Send(ds.p + so, (size_t)send_bytes[r], Rccl::kInt8, r, c->comm, c->stream);
+                if (nrc == 0 && recv_bytes[r])
+                    nrc = g_rccl.Recv(dr.p + ro, (size_t)recv_bytes[r], Rccl::kInt8, r, c->comm, c->stream);
+                so += send_bytes[r];
+                ro += recv_bytes[r];
+            }
+            const int end = g_rccl.GroupEnd();
+            if (nrc == 0)
+                nrc = end;
+        }
+        if (e == hipSuccess && nrc == 0 && nr)
+            e = hipMemcpyAsync(recv, dr.p, nr, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(c->stream);
+        else
+            (void)hipStreamSynchronize(c->stream);
+        ds.release();
+        dr.release();
+        if (nrc != 0)
+            rc = fail(c, ICP_HIP_ERR_COMM,
+                      std::string("ncclSend/ncclRecv: ") +
+                          (g_rccl.GetErrorString ? g_rccl.GetErrorString(nrc) : "error"));
+        else if (e != hipSuccess)
+            rc = hip_fail(c, e, "icp_hip_set_queries_exchange: staging copy");
+        return rc;
+    }
+
+    // The moved points of an exchanged shard go back to the ranks whose rows they are: the
+    // reverse of the set-up exchange (collective: every rank calls icp_hip_get_points).
+    int get_points_exchanged(icp_hip_ctx* c, float* xyz_aos)
+    {
+        const int R = (int)c->ex_sent.size();
+        if (c->ex_n_caller != 0 && !xyz_aos)
+            return fail(c, ICP_HIP_ERR_ARG, "icp_hip_get_points: xyz_aos is NULL");
+        std::vector<float> mine(3 * (size_t)c->n_local + 3), back(3 * (size_t)c->ex_n_caller + 3);
+        int rc = get_points_local(c, mine.data());
+        if (rc != ICP_HIP_OK)
+            return rc;
+        std::vector<uint64_t> sb(R), rb(R);
+        for (int r = 0; r < R; ++r)
+        {
+            sb[r] = c->ex_got[r] * 12ull;  // what came from rank r goes back to it, in that order
+            rb[r] = c->ex_sent[r] * 12ull;
+        }
+        if ((rc = exchange_blocks(c, mine.data(), sb.data(), back.data(), rb.data(), R)) != ICP_HIP_OK)
+            return rc;
+        for (uint64_t k = 0; k < c->ex_n_caller; ++k)
+        {
+            const size_t row = c->ex_rows[k];
+            xyz_aos[3 * row] = back[3 * k];
+            xyz_aos[3 * row + 1] = back[3 * k + 1];
+            xyz_aos[3 * row + 2] = back[3 * k + 2];
+        }
+        return ICP_HIP_OK;
+    }
 } // namespace
 
 extern "C"
@@ -2052,6 +2201,7 @@ extern "C"
             return fail(c, ICP_HIP_ERR_ARG, "icp_hip_set_queries: shard larger than 2^31-1 points");
         DeviceGuard g(c->device);
         c->has_queries = false;
+        c->exchanged = false;
         c->upload_pending = c->host_points_valid = c->first_sums_valid = false;
         c->leaf_ordered = c->resorted = c->resort_decided = false;
         const size_t n = n_local ? n_local : 1;
@@ -2149,11 +2299,229 @@ extern "C"
         return prepare_tile(c);
     }
 
+    int icp_hip_get_shard_size(icp_hip_ctx* c, uint64_t* n_local, uint64_t* n_total)
+    {
+        if (!c || !c->has_queries)
+            return fail(c, ICP_HIP_ERR_ARG, "icp_hip_get_shard_size: no query shard set");
+        if (n_local)
+            *n_local = c->n_local;
+        if (n_total)
+            *n_total = c->n_total;
+        return ICP_HIP_OK;
+    }
+
+    int icp_hip_set_alltoallv(icp_hip_ctx* c, int n_ranks, int rank, icp_hip_alltoallv_fn fn,
+                              void* user)
+    {
+        if (!c)
+            return fail(nullptr, ICP_HIP_ERR_ARG, "icp_hip_set_alltoallv: ctx is NULL");
+        if (fn && (n_ranks < 1 || rank < 0 || rank >= n_ranks))
+            return fail(c, ICP_HIP_ERR_ARG, "icp_hip_set_alltoallv: bad n_ranks / rank");
+        c->alltoallv = fn;
+        c->alltoallv_user = user;
+        c->ex_ranks = fn ? n_ranks : 0;
+        c->ex_rank = fn ? rank : 0;
+        return ICP_HIP_OK;
+    }
+
+    int icp_hip_set_queries_exchange(icp_hip_ctx* c, const float* xyz_aos, uint64_t n_local,
+                                     uint64_t n_total)
+    {
+        if (!c)
+            return fail(nullptr, ICP_HIP_ERR_ARG, "icp_hip_set_queries_exchange: ctx is NULL");
+        if (n_local > 0 && !xyz_aos)
+            return fail(c, ICP_HIP_ERR_ARG, "icp_hip_set_queries_exchange: xyz_aos is NULL");
+        if (n_total < n_local || n_total == 0 || n_local >= (1ull << 31))
+            return fail(c, ICP_HIP_ERR_ARG, "icp_hip_set_queries_exchange: bad n_local / n_total");
+        const int R = c->alltoallv ? c->ex_ranks : c->comm ? c->n_ranks : 1;
+        // (ICP_HIP_EXCHANGE_SELF=1: a single rank goes through the exchange too, sending to itself
+        // -- the only way to run the ncclSend / ncclRecv leg on a box with one GPU; tests)
+        const char* self_env = std::getenv("ICP_HIP_EXCHANGE_SELF");
+        if (R <= 1 && !(self_env && self_env[0] == '1' && (c->alltoallv || c->comm)))
+            return icp_hip_set_queries(c, xyz_aos, n_local, n_total);
+        if (!icp_host::all_finite(xyz_aos, 3 * n_local))
+            return fail(c, ICP_HIP_ERR_ARG,
+                        std::string("icp_hip_set_queries_exchange: ") + icp_host::kNonFiniteMessage);
+        DeviceGuard g(c->device);
+        int rc;
+        // 1. the ranks' row counts (and coordinate sums), all to all: n_total is checked
+        std::vector<uint64_t> b32(R, 32);
+        std::vector<double> mine4(4 * (size_t)R), all4(4 * (size_t)R);
+        {
+            double s[4] = {(double)n_local, 0.0, 0.0, 0.0};
+            for (uint64_t i = 0; i < n_local; ++i)
+            {
+                s[1] += (double)xyz_aos[3 * i];
+                s[2] += (double)xyz_aos[3 * i + 1];
+                s[3] += (double)xyz_aos[3 * i + 2];
+            }
+            for (int r = 0; r < R; ++r)
+                std::memcpy(&mine4[4 * (size_t)r], s, sizeof s);
+        }
+        if ((rc = exchange_blocks(c, mine4.data(), b32.data(), all4.data(), b32.data(), R)) != ICP_HIP_OK)
+            return rc;
+        double tot[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int r = 0; r < R; ++r)
+            for (int k = 0; k < 4; ++k)
+                tot[k] += all4[4 * (size_t)r + k];
+        if ((uint64_t)tot[0] != n_total)
+            return fail(c, ICP_HIP_ERR_ARG,
+                        "icp_hip_set_queries_exchange: the ranks' n_local add up to " +
+                            std::to_string((uint64_t)tot[0]) + ", not to n_total = " +
+                            std::to_string(n_total));
+        // 2. a sample of the whole cloud on every rank: each rank sends the same evenly spaced
+        //    kSample of its rows to everybody (a rank with fewer sends them all)
+        constexpr uint64_t kSample = 16384;
+        const uint64_t my_s = std::min<uint64_t>(n_local, kSample);
+        std::vector<uint64_t> s_cnt(R, my_s), s_got(R, 0), b8s(R, 8);
+        if ((rc = exchange_blocks(c, s_cnt.data(), b8s.data(), s_got.data(), b8s.data(), R)) != ICP_HIP_OK)
+            return rc;
+        uint64_t n_samp = 0;
+        std::vector<uint64_t> ssb(R, my_s * 12ull), srb(R);
+        for (int r = 0; r < R; ++r)
+        {
+            if (s_got[r] > kSample)
+                return fail(c, ICP_HIP_ERR_COMM, "icp_hip_set_queries_exchange: bad sample size from a rank");
+            srb[r] = s_got[r] * 12ull;
+            n_samp += s_got[r];
+        }
+        std::vector<float> samp_send(3 * (size_t)my_s * R + 3), samp(3 * (size_t)n_samp + 3);
+        for (uint64_t k = 0; k < my_s; ++k)
+        {
+            const uint64_t i = k * n_local / my_s;
+            for (int r = 0; r < R; ++r)
+                std::memcpy(&samp_send[3 * ((size_t)r * my_s + k)], xyz_aos + 3 * i, 12);
+        }
+        if ((rc = exchange_blocks(c, samp_send.data(), ssb.data(), samp.data(), srb.data(), R)) != ICP_HIP_OK)
+            return rc;
+        // 3. R spatially compact regions of about equal size: planes perpendicular to x, y, z in
+        //    turn, each at the quantile of the sample that leaves both sides their share of the
+        //    ranks (every rank computes the same planes from the same sample); a rank searches
+        //    the whole tree for its region, and a compact region costs it about its share of
+        //    the one-GPU pass (boxes: 1.0-1.15x; the tree's own top-level regions, balls and
+        //    shells with more surface: 1.1-1.3x; a slice of unordered rows: 1.5-1.75x)
+        struct Cut
+        {
+            int axis;
+            float at;
+            int below, above; // >= 0: index of the next cut; < 0: ~rank
+        };
+        std::vector<Cut> cuts;
+        {
+            std::vector<uint32_t> idx(n_samp);
+            for (uint64_t k = 0; k < n_samp; ++k)
+                idx[k] = (uint32_t)k;
+            // (iterative: ranges of the index array with their rank interval and axis)
+            struct Job
+            {
+                size_t b, e;
+                int lo, hi, axis, slot; // slot: where to write this subtree's id (-1: root)
+                bool above;
+            };
+            std::vector<Job> jobs{{0, (size_t)n_samp, 0, R, 0, -1, false}};
+            while (!jobs.empty())
+            {
+                const Job j = jobs.back();
+                jobs.pop_back();
+                int id;
+                if (j.hi - j.lo <= 1)
+                    id = ~j.lo;
+                else
+                {
+                    const int mid = j.lo + (j.hi - j.lo) / 2;
+                    const size_t len = j.e - j.b;
+                    size_t k = len * (size_t)(mid - j.lo) / (size_t)(j.hi - j.lo);
+                    float at = 0.f;
+                    if (len)
+                    {
+                        k = std::min(k, len - 1);
+                        std::nth_element(idx.begin() + j.b, idx.begin() + j.b + k, idx.begin() + j.e,
+                                         [&](uint32_t a, uint32_t b2) {
+                                             const float va = samp[3 * (size_t)a + j.axis],
+                                                         vb = samp[3 * (size_t)b2 + j.axis];
+                                             return va < vb || (va == vb && a < b2);
+                                         });
+                        at = samp[3 * (size_t)idx[j.b + k] + j.axis];
+                    }
+                    id = (int)cuts.size();
+                    cuts.push_back({j.axis, at, 0, 0});
+                    // strictly below the cut value goes below (ties go above, like the sample's k-th)
+                    size_t split = j.b;
+                    if (len)
+                        split = std::partition(idx.begin() + j.b, idx.begin() + j.e,
+                                               [&](uint32_t a) { return samp[3 * (size_t)a + j.axis] < at; }) -
+                                idx.begin();
+                    jobs.push_back({j.b, split, j.lo, mid, (j.axis + 1) % 3, id, false});
+                    jobs.push_back({split, j.e, mid, j.hi, (j.axis + 1) % 3, id, true});
+                }
+                if (j.slot >= 0)
+                    (j.above ? cuts[j.slot].above : cuts[j.slot].below) = id;
+            }
+        }
+        std::vector<uint32_t> owner(n_local ? n_local : 1);
+        std::vector<uint64_t> cnt(R, 0);
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < (int64_t)n_local; ++i)
+        {
+            int id = cuts.empty() ? ~0 : 0;
+            while (id >= 0)
+            {
+                const Cut& q = cuts[id];
+                id = xyz_aos[3 * i + q.axis] < q.at ? q.below : q.above;
+            }
+            owner[i] = (uint32_t)~id;
+        }
+        for (uint64_t i = 0; i < n_local; ++i)
+            cnt[owner[i]] += 1;
+        // 4. how many points every rank gets from every rank, then the points themselves
+        //    (x, y, z; the caller's row stays here, in send order)
+        std::vector<uint64_t> b8(R, 8), got(R, 0);
+        if ((rc = exchange_blocks(c, cnt.data(), b8.data(), got.data(), b8.data(), R)) != ICP_HIP_OK)
+            return rc;
+        std::vector<uint64_t> at(R, 0), sb(R), rb(R);
+        uint64_t n_recv = 0;
+        for (int r = 0; r < R; ++r)
+        {
+            at[r] = r ? at[r - 1] + cnt[r - 1] : 0;
+            sb[r] = cnt[r] * 12ull;
+            rb[r] = got[r] * 12ull;
+            n_recv += got[r];
+        }
+        if (n_recv >= (1ull << 31))
+            return fail(c, ICP_HIP_ERR_ARG, "icp_hip_set_queries_exchange: region larger than 2^31-1 points");
+        std::vector<float> send(3 * (size_t)n_local + 3), recv(3 * (size_t)n_recv + 3);
+        std::vector<uint32_t> rows(n_local ? n_local : 1);
+        for (uint64_t i = 0; i < n_local; ++i)
+        {
+            const uint64_t k = at[owner[i]]++;
+            send[3 * k] = xyz_aos[3 * i];
+            send[3 * k + 1] = xyz_aos[3 * i + 1];
+            send[3 * k + 2] = xyz_aos[3 * i + 2];
+            rows[k] = (uint32_t)i;
+        }
+        if ((rc = exchange_blocks(c, send.data(), sb.data(), recv.data(), rb.data(), R)) != ICP_HIP_OK)
+            return rc;
+        // 5. from here on this rank registers the points of its region
+        if ((rc = icp_hip_set_queries(c, recv.data(), n_recv, n_total)) != ICP_HIP_OK)
+            return rc;
+        c->exchanged = true;
+        c->ex_n_caller = n_local;
+        c->ex_sent = cnt;
+        c->ex_got = got;
+        rows.resize(n_local);
+        c->ex_rows = std::move(rows);
+        return ICP_HIP_OK;
+    }
+
     int icp_hip_nn(icp_hip_ctx* c, const float mu_p[3], uint32_t* row_out, float* xyz_out,
                    float* dist_out, float* kernel_ms)
     {
         if (!c || !mu_p)
             return fail(c, ICP_HIP_ERR_ARG, "icp_hip_nn: NULL argument");
+        if (c->exchanged && (row_out || xyz_out || dist_out))
+            return fail(c, ICP_HIP_ERR_ARG,
+                        "icp_hip_nn: per-query outputs are not available for a shard that was "
+                        "exchanged between the ranks (icp_hip_set_queries_exchange)");
         if (!c->has_tree || !c->has_queries)
             return fail(c, ICP_HIP_ERR_ARG, "icp_hip_nn: set_tree and set_queries must come first");
         DeviceGuard g(c->device);
@@ -2306,6 +2674,7 @@ extern "C"
                             (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"));
         }
         c->n_ranks = n_ranks;
+        c->rank = rank;
         return ICP_HIP_OK;
     }
 
@@ -2348,40 +2717,9 @@ extern "C"
     {
         if (!c || !c->has_queries)
             return fail(c, ICP_HIP_ERR_ARG, "icp_hip_get_points: no query shard set");
-        if (c->n_local == 0)
-            return ICP_HIP_OK;
-        if (!xyz_aos)
-            return fail(c, ICP_HIP_ERR_ARG, "icp_hip_get_points: xyz_aos is NULL");
-        DeviceGuard g(c->device);
-        const uint32_t n = (uint32_t)c->n_local;
-        if (c->small && c->host_points_valid)
-        {
-            // the last registration brought the block back with its state: nothing to wait for
-            const float* hx = reinterpret_cast<const float*>(c->h_down + kSmallHead);
-            const float *hy = hx + c->small_pad, *hz = hy + c->small_pad;
-            for (uint32_t i = 0; i < n; ++i)
-            {
-                xyz_aos[3 * (size_t)i] = hx[i];
-                xyz_aos[3 * (size_t)i + 1] = hy[i];
-                xyz_aos[3 * (size_t)i + 2] = hz[i];
-            }
-            return ICP_HIP_OK;
-        }
-        {
-            int rc = flush_queries(c);
-            if (rc != ICP_HIP_OK)
-                return rc;
-        }
-        HIP_TRY(c, c->aos.alloc(3ull * n));
-        if (c->sorted)
-            HIP_TRY(c, launch_scatter_aos(c->px.p, c->py.p, c->pz.p, c->perm.p, n, c->aos.p,
-                                          c->stream));
-        else
-            HIP_TRY(c, launch_soa_to_aos(c->px.p, c->py.p, c->pz.p, n, c->aos.p, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(xyz_aos, c->aos.p, 3ull * n * sizeof(float),
-                                  hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        return ICP_HIP_OK;
+        if (c->exchanged)
+            return get_points_exchanged(c, xyz_aos);
+        return get_points_local(c, xyz_aos);
     }
 
     int icp_hip_icp(icp_hip_ctx* c, const float* m_xyz, uint64_t n_m, const float* p_xyz,

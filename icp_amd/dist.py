@@ -62,6 +62,33 @@ def torch_allreduce(group=None, device=None):
     return fn
 
 
+def torch_alltoallv(group=None, device=None):
+    """Callable for Context.set_alltoallv: variable-size blocks of bytes between the ranks of the
+    process group (gloo on CPU tensors; nccl == RCCL when `device` is a cuda device)."""
+    import torch
+    import torch.distributed as dist
+
+    def fn(send: np.ndarray, send_bytes, recv_bytes) -> np.ndarray:
+        world = len(send_bytes)
+        ins, at = [], 0
+        for b in send_bytes:
+            t = torch.from_numpy(np.array(send[at:at + b], np.uint8))
+            ins.append(t.to(device) if device is not None else t)
+            at += b
+        outs = [torch.empty(b, dtype=torch.uint8, device=device) for b in recv_bytes]
+        # (gloo has no all-to-all of uneven blocks: world rounds of broadcasts would do too, but
+        # point-to-point sends in a fixed order are enough here and never deadlock: everybody
+        # posts its receives first)
+        rank = dist.get_rank(group)
+        reqs = [dist.irecv(outs[r], src=r, group=group) for r in range(world) if r != rank and recv_bytes[r]]
+        reqs += [dist.isend(ins[r], dst=r, group=group) for r in range(world) if r != rank and send_bytes[r]]
+        outs[rank].copy_(ins[rank])
+        for q in reqs:
+            q.wait()
+        return np.concatenate([o.cpu().numpy() for o in outs]) if world else np.empty(0, np.uint8)
+    return fn
+
+
 def init_rccl(ctx, world: int, rank: int) -> None:
     """Create the context's own RCCL communicator: rank 0 makes the ncclUniqueId, the process
     group distributes it."""

@@ -170,6 +170,34 @@ int icp_hip_get_tree_info(icp_hip_ctx* ctx, icp_flat_tree* out);
 int icp_hip_set_queries(icp_hip_ctx* ctx, const float* xyz_aos, uint64_t n_local,
                         uint64_t n_total);
 
+/* The same for a rank that CANNOT choose its rows ("GPU g holds query rows
+ * [g n/G, (g+1) n/G)", whatever order the cloud comes in).  No counterpart in the reference
+ * (single device).  Collective: every rank calls it with its rows.  The ranks exchange points so
+ * that each registers one spatially compact region of about equal size -- the cloud cut by
+ * planes perpendicular to x, y, z in turn, at the quantiles of a sample of 16384 rows per rank
+ * that every rank sees -- which costs a rank about its share of the one-GPU pass, where an
+ * arbitrary slice of rows costs 1.5-1.75x.  Afterwards icp_hip_run works as after icp_hip_set_queries, and
+ * icp_hip_get_points is collective too: the moved points travel back and land in the rows the
+ * caller handed over here.  icp_hip_nn's per-query outputs are not available on such a shard.
+ * The points travel through the callback of icp_hip_set_alltoallv or, without one, through the
+ * RCCL communicator (ncclSend / ncclRecv on staging buffers).  One rank: icp_hip_set_queries. */
+int icp_hip_set_queries_exchange(icp_hip_ctx* ctx, const float* xyz_aos, uint64_t n_local,
+                                 uint64_t n_total);
+
+/* The shard this context registers right now: *n_local points of a cloud of *n_total (after
+ * icp_hip_set_queries_exchange n_local is the size of the rank's region, not of the rows it handed
+ * over).  Diagnostic (load balance of a sharded run); no counterpart in the reference. */
+int icp_hip_get_shard_size(icp_hip_ctx* ctx, uint64_t* n_local, uint64_t* n_total);
+
+/* All-to-all of variable-size blocks on host memory, supplied by the caller (tests: gloo; MPI):
+ * `send` holds the blocks for ranks 0 .. n_ranks-1 back to back (send_bytes[r] each), `recv`
+ * receives the blocks from ranks 0 .. n_ranks-1 back to back (recv_bytes[r] each; the library
+ * knows them beforehand).  Returns 0 on success.  No counterpart in the reference. */
+typedef int (*icp_hip_alltoallv_fn)(const void* send, const uint64_t* send_bytes, void* recv,
+                                    const uint64_t* recv_bytes, int n_ranks, void* user);
+int icp_hip_set_alltoallv(icp_hip_ctx* ctx, int n_ranks, int rank, icp_hip_alltoallv_fn fn,
+                          void* user);
+
 /* One batch nearest-neighbour pass over the shard: query_i = p_i - mu_p.
  * Replaces GPUVPTree::closest / closest_kernel (libgpu/libgpu/vp-tree.cu:181-261), with the
  * CPU rules of VPTree::search (libcpu/libcpu/vp-tree.cc:125-175).

@@ -106,6 +106,27 @@ def main():
             new_p = ctx.get_points()
         np.savez(f"{out_path}.{rank}.npz", rows=rows, new_p=new_p)
         result.update(T=[float(v) for v in T.reshape(-1)], iters=int(iters), err=float(err))
+    elif mode == "gpu_exchange":
+        # SURVEY 8e's contract: every rank hands over a contiguous slice of the cloud's rows (in
+        # whatever order the cloud comes: here a random one) and the library re-partitions
+        # behind the ABI (icp_hip_set_queries_exchange, points travelling over gloo through the
+        # all-to-all callback); get_points brings every rank ITS rows back
+        from icp_amd.dist import torch_alltoallv
+        n2 = 400_000
+        m2 = synth.cloud(n2, seed=23)
+        p2 = synth.apply_fp32(m2, synth.ground_truth(1.0))
+        b2, e2 = shard_bounds(n2, world, rank)
+        mu_m = capi.mean_host(m2)
+        with capi.Context(0) as ctx:
+            ctx.build_tree(capi.center_host(m2, mu_m), 256)
+            ctx.set_alltoallv(world, rank, torch_alltoallv())
+            ctx.set_allreduce(allreduce)
+            ctx.set_queries_exchange(p2[b2:e2], n_total=n2)
+            T, iters, err = ctx.run(mu_m, 30, 1e-5)
+            new_p = ctx.get_points()
+            local = ctx.shard_size()[0]  # the size of this rank's region
+        np.savez(f"{out_path}.{rank}.npz", rows=np.arange(b2, e2), new_p=new_p)
+        result.update(T=[float(v) for v in T.reshape(-1)], iters=int(iters), err=float(err), queries=local)
     else:
         # real GPU, both ranks on device 0, sums exchanged over gloo through the C-ABI callback
         mu_m = capi.mean_host(m)

@@ -49,6 +49,32 @@ def test_spatially_compact_shards_match_one_context(tmp_path):
     assert np.abs(out - new_p1).max() <= 1e-6
 
 
+def test_rows_exchanged_behind_the_abi_match_one_context(tmp_path):
+    """icp_hip_set_queries_exchange: each rank hands over a contiguous slice of the (randomly
+    ordered) rows, the library sends every point to the rank that owns its region of the tree,
+    and icp_hip_get_points returns to every rank the rows it handed over: the single-context
+    registration, up to the order of the fp64 sums."""
+    import icp_amd
+    from icp_amd import synth
+    n = 400_000
+    m = synth.cloud(n, seed=23)
+    p = synth.apply_fp32(m, synth.ground_truth(1.0))
+    T1, new_p1, info = icp_amd.icp(m, p, 30, 1e-5, 256, return_info=True)
+    res = run_workers("gpu_exchange", str(tmp_path / "out"))
+    out = np.full_like(new_p1, np.nan)
+    for r in res:
+        assert r["iters"] == info["iterations"]
+        assert np.abs(np.array(r["T"], np.float32).reshape(4, 4) - T1).max() <= 1e-6
+        z = np.load(str(tmp_path / "out") + f".{r['rank']}.npz")
+        assert len(z["new_p"]) == len(z["rows"])
+        out[z["rows"]] = z["new_p"]
+    assert res[0]["T"] == res[1]["T"]
+    assert np.abs(out - new_p1).max() <= 1e-6
+    # the regions cover the cloud and are about equal (quantiles of a 32768-point sample)
+    assert sum(r["queries"] for r in res) == n
+    assert max(r["queries"] for r in res) <= 1.03 * n / 2
+
+
 def test_empty_shard_takes_part_in_every_collective(tmp_path):
     """More ranks than points: a rank with an empty shard issues the same all-reduces and ends
     with the same transform."""
@@ -180,6 +206,53 @@ def test_bench_flow_with_two_ranks_sharing_the_gpu():
     rf = j["roofline"]
     assert rf["bound"] == "valu_issue" and rf["avg_launch_ms"] > 0
     assert rf["frac"] is None and rf["traffic"] is None and "no committed counter passes" in rf["note"]
+
+
+def test_exchange_over_rccl_with_one_rank(monkeypatch):
+    """The ncclSend / ncclRecv leg of icp_hip_set_queries_exchange (staging buffers in HBM, one
+    group of sends and receives): a communicator of one rank exchanging with itself
+    (ICP_HIP_EXCHANGE_SELF=1) -- all this box can start.  Nothing moves, so the registration and
+    the rows that come back are those of icp_hip_set_queries under the same communicator, bit for
+    bit; per-query outputs of icp_hip_nn are refused on the exchanged shard."""
+    from icp_amd import capi, synth
+    n = 120_000
+    m = synth.cloud(n, seed=37)
+    p = synth.apply_fp32(m, synth.ground_truth(1.5))
+    mu_m = capi.mean_host(m)
+    mc = capi.center_host(m, mu_m)
+    out = []
+    for exchange in (False, True):
+        with capi.Context() as ctx:
+            ctx.build_tree(mc, 64)
+            ctx.comm_init_rank(1, 0, capi.Context.comm_unique_id())
+            if exchange:
+                monkeypatch.setenv("ICP_HIP_EXCHANGE_SELF", "1")
+                ctx.set_queries_exchange(p, n_total=n)
+                assert ctx.shard_size() == (n, n)
+                with pytest.raises(capi.IcpHipError):
+                    ctx.nn(mu_m)
+                ctx.nn(mu_m, want=())
+                ctx.set_queries_exchange(p, n_total=n)
+            else:
+                ctx.set_queries(p)
+            T, iters, err = ctx.run(mu_m, 20, 1e-5)
+            out.append((T.copy(), iters, err, ctx.get_points()))
+    assert out[0][1] == out[1][1] and out[0][2] == out[1][2]
+    assert (out[0][0].view(np.uint32) == out[1][0].view(np.uint32)).all()
+    assert (out[0][3].view(np.uint32) == out[1][3].view(np.uint32)).all()
+
+
+def test_bench_rows_exchange_partition():
+    """bench.py --gpus 2 --partition rows-exchange on the shared GPU: contiguous row slices in,
+    compact regions of about equal size registered, the same transform."""
+    import json
+    r = _bench_two_ranks({}, ("--partition", "rows-exchange"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert "icp_hip_set_queries_exchange" in j["config"]["shards"]
+    sizes = [p["queries"] for p in j["per_rank"]]
+    assert sum(sizes) == 100000 and max(sizes) <= 52000
+    assert j["check"]["max_abs_T_minus_expected"] < 5e-5
 
 
 def _bench_two_ranks(extra_env, extra_args=()):
