@@ -637,7 +637,7 @@ namespace icp_dev
             // instead of riding in registers through the batch.
             auto lot_at = [&](uint32_t which, uint32_t e) -> uint32_t* {
                 uint32_t tid = threadIdx.x;
-                asm volatile("" : "+v"(tid));
+                asm volatile("" : "+v"(tid), "+v"(e));
                 return cold()->park +
                        ((size_t)((blockIdx.x * (uint32_t)kWavesPerBlock + (tid >> 6)) * 2u + which) * (kLot * kParkWords) + e);
             };
@@ -1403,9 +1403,11 @@ namespace icp_dev
 #pragma unroll
                     for (int k = 0; k < 3; ++k) // rows: v4k, v4k+2, v4k+1, v4k+3
                         r[k] = row_sum_f64(swap_add_rows(h[2 * k], h[2 * k + 1]));
-                    if ((lane & 15) == 15) // the last lane of a row holds the row's sum
+                    uint32_t lane_s = (uint32_t)lane; // (opaque: the address below is made here)
+                    asm volatile("" : "+v"(lane_s));
+                    if ((lane_s & 15u) == 15u) // the last lane of a row holds the row's sum
                     {
-                        const int row = lane >> 4;
+                        const int row = (int)(lane_s >> 4);
                         const int k0 = ((row & 1) << 1) | (row >> 1);
 #pragma unroll
                         for (int k = 0; k < 3; ++k)
