@@ -812,6 +812,7 @@ namespace icp_dev
                 __builtin_amdgcn_s_setprio(1);
                 if (t.root >= 0 && !flush)
                 {
+                    uint32_t depth = 0; // wave-uniform: levels gone down
                     for (;;)
                     {
                         const bool going = mode == tDescend;
@@ -829,7 +830,8 @@ namespace icp_dev
                         // written while a pass runs) instead of 64 lanes x 32 bytes through the
                         // vector memory pipe, which the bucket images need.
                         const int node0 = __builtin_amdgcn_readlane(node, (int)__builtin_ctzll(goers));
-                        const bool same = __ballot(going && node != node0) == 0ull;
+                        const bool same = (__ballot(node != node0) & goers) == 0ull;
+                        depth += 1u;
                         if (going)
                         {
                             typedef uint32_t u4 __attribute__((ext_vector_type(4)));
@@ -850,7 +852,6 @@ namespace icp_dev
                             }
                             else
                                 N = t.nodes[node];
-                            n_int += 1u;
                             const float d2 = sq_dist(qx, qy, qz, N.cx, N.cy, N.cz);
                             const float da = __builtin_amdgcn_sqrtf(d2); // as in the general step
                             const float lb = __fsub_rn(
@@ -868,6 +869,7 @@ namespace icp_dev
                                 lbeg = li.x;
                                 lcnt = li.y;
                                 n_pts += li.y;
+                                n_int += depth; // (every level down to here was a node visited)
                                 prev = go;
                                 mode = tWaitLeaf;
                             }
