@@ -253,7 +253,6 @@ namespace
 } // namespace
 
 constexpr uint64_t kParkMinPoints = 6'000'000;       // shards from which the straggler lots pay once aligned
-constexpr uint64_t kParkMinPointsEarly = 40'000'000; // ... and while the clouds are still apart
 
 struct icp_hip_ctx
 {
@@ -328,11 +327,13 @@ struct icp_hip_ctx
     // When: measured on one MI355X (scripts/park_probe.py, bench.py): once the clouds are aligned
     // the pass is 9-13 % faster from 16M points up, 3 % at 8M, and SLOWER below (every wave ends
     // with a batch of what is left in its lot, which weighs on a short pass); while the clouds
-    // are still a point spacing apart it is 5 % faster at 64M points, even at 32M and 9 % slower
-    // at 16M (best there with up to 16 lanes parked per batch, 8 late rows per batch; aligned: 8
-    // and 2).  So the lots are used on shards of kParkMinPoints and more in the passes after the
+    // are still a point spacing apart it is 5 % faster at 64M points (best with up to 16 lanes
+    // parked per batch and 8 late rows per batch), even at 32M and 9 % slower at 16M -- and it
+    // fetches 26 GB per 64M pass instead of 9.3: the parked queries of a misaligned batch come
+    // back in batches that stage buckets from all over the tree, each for one lane.  Not worth
+    // it.  So the lots are used on shards of kParkMinPoints and more, in the passes after the
     // second ordering pass (maybe_resort: the registration's own sign that the clouds are
-    // aligned), and from kParkMinPointsEarly in the passes before it.
+    // aligned; +0.8 GB fetched and +0.13 GB written per 64M pass, for 10 % of its time).
     // ICP_HIP_PARK=always / never and ICP_HIP_PARK_MAX / ICP_HIP_LATE_PER_BATCH override (tests,
     // experiments).
     uint32_t park_max_env = 0, late_per_batch_env = 0; // 0: not set
@@ -341,14 +342,13 @@ struct icp_hip_ctx
     bool park_ready = false;      // lots and late rows are allocated for the current launch shape
     bool park_now() const
     {
-        return park_ready && (park_mode == 1 || resorted || n_local >= kParkMinPointsEarly);
+        return park_ready && (park_mode == 1 || resorted);
     }
     uint32_t park_max() const { return park_max_env ? park_max_env : resorted ? 8u : 16u; }
     uint32_t late_per_batch() const { return late_per_batch_env ? late_per_batch_env : resorted ? 2u : 8u; }
     uint32_t late_per_batch_most() const
     {
-        return late_per_batch_env ? late_per_batch_env
-                                  : (park_mode == 1 || n_local >= kParkMinPointsEarly) ? 8u : 2u;
+        return late_per_batch_env ? late_per_batch_env : park_mode == 1 ? 8u : 2u;
     }
     uint32_t late_rows() const { return late_per_batch() * chunk_batches; }
 

@@ -143,7 +143,7 @@ namespace icp_dev
         uint32_t park_wait = 0; // rounds (node + leaf phase) a batch goes on with <= park_max lanes
                                 // at work before it parks them: short excursions end in place
     };
-    constexpr uint32_t kParkLotWords = 64 * 22; // words of ONE lot; a wave has two (nn_tile.hip asserts the size)
+    constexpr uint32_t kParkLotWords = 64 * 24; // words of ONE lot; a wave has two (nn_tile.hip asserts the size)
     constexpr uint32_t kParkMaxLanes = 32;
     hipError_t launch_nn_tile(const NnLaunch& a, const TileLaunch& q, hipStream_t s);
     // How a shard of n queries is laid on a grid of at most max_blocks resident workgroups.

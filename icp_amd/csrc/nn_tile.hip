@@ -72,8 +72,12 @@ namespace icp_dev
         {
             pkQx = 0, pkQy, pkQz, pkNode, pkPrev, pkModeSp, pkRd, pkRid, pkChainM, pkChainM2, pkArg,
             pkRetNode, pkTop, pkNInt, pkNPts, pkOvf, pkIndex, pkRow, pkStD0, pkStI0, pkStD1, pkStI1,
-            kParkWords
+            kParkFields,
+            kParkWords = 24 // an entry = 96 bytes, its fields side by side: the stores of a lane
+                            // that is parked fall into one or two cache lines and merge in L2
+                            // (field by field over the lot they were 22 partial lines per lane)
         };
+        static_assert(kParkFields <= kParkWords, "lot entry");
         static_assert(kStackK == 2, "the lot keeps two stack entries per parked lane");
         static_assert(kLot * kParkWords == kParkLotWords, "kernels.hh sizes the lots");
         constexpr int kTileSplitBelow = 56; // 33..55 lanes: scan as 32 + rest (see the leaf phase)
@@ -639,7 +643,8 @@ namespace icp_dev
                 uint32_t tid = threadIdx.x;
                 asm volatile("" : "+v"(tid), "+v"(e));
                 return cold()->park +
-                       ((size_t)((blockIdx.x * (uint32_t)kWavesPerBlock + (tid >> 6)) * 2u + which) * (kLot * kParkWords) + e);
+                       ((size_t)((blockIdx.x * (uint32_t)kWavesPerBlock + (tid >> 6)) * 2u + which) * (kLot * kParkWords) +
+                        (size_t)e * kParkWords);
             };
             uint32_t cur = 0; // wave-uniform: the lot that takes parked queries
             uint32_t lot = 0;     // wave-uniform: entries in the lot
@@ -763,28 +768,28 @@ namespace icp_dev
                     if (valid)
                     {
                         const uint32_t* e = lot_at(cur, (uint32_t)lane);
-                        qx = __uint_as_float(e[pkQx * kLot]);
-                        qy = __uint_as_float(e[pkQy * kLot]);
-                        qz = __uint_as_float(e[pkQz * kLot]);
-                        node = (int)e[pkNode * kLot];
-                        prev = (int)e[pkPrev * kLot];
-                        const uint32_t ms = e[pkModeSp * kLot];
+                        qx = __uint_as_float(e[pkQx]);
+                        qy = __uint_as_float(e[pkQy]);
+                        qz = __uint_as_float(e[pkQz]);
+                        node = (int)e[pkNode];
+                        prev = (int)e[pkPrev];
+                        const uint32_t ms = e[pkModeSp];
                         mode = (int)(ms & 0xFFu);
                         sp = ms >> 8;
-                        rd = __uint_as_float(e[pkRd * kLot]);
-                        rid = e[pkRid * kLot];
-                        chain_m = __uint_as_float(e[pkChainM * kLot]);
-                        chain_m2 = __uint_as_float(e[pkChainM2 * kLot]);
-                        arg = (int)e[pkArg * kLot];
-                        ret_node = (int)e[pkRetNode * kLot];
-                        top = (int)e[pkTop * kLot];
-                        n_int = e[pkNInt * kLot];
-                        n_pts = e[pkNPts * kLot];
-                        ovf = e[pkOvf * kLot];
-                        st_d[0] = __uint_as_float(e[pkStD0 * kLot]);
-                        st_i[0] = e[pkStI0 * kLot];
-                        st_d[kWave] = __uint_as_float(e[pkStD1 * kLot]);
-                        st_i[kWave] = e[pkStI1 * kLot];
+                        rd = __uint_as_float(e[pkRd]);
+                        rid = e[pkRid];
+                        chain_m = __uint_as_float(e[pkChainM]);
+                        chain_m2 = __uint_as_float(e[pkChainM2]);
+                        arg = (int)e[pkArg];
+                        ret_node = (int)e[pkRetNode];
+                        top = (int)e[pkTop];
+                        n_int = e[pkNInt];
+                        n_pts = e[pkNPts];
+                        ovf = e[pkOvf];
+                        st_d[0] = __uint_as_float(e[pkStD0]);
+                        st_i[0] = e[pkStI0];
+                        st_d[kWave] = __uint_as_float(e[pkStD1]);
+                        st_i[kWave] = e[pkStI1];
                     }
                     lot = 0;
                     cur ^= 1u; // (what this batch parks again goes to the other lot)
@@ -905,36 +910,36 @@ namespace icp_dev
                                     if (flush)
                                     {
                                         const uint32_t* from = lot_at(cur ^ 1u, (uint32_t)lane);
-                                        i = from[pkIndex * kLot];
-                                        late_row = from[pkRow * kLot];
+                                        i = from[pkIndex];
+                                        late_row = from[pkRow];
                                     }
                                     else
                                     {
                                         i = b * batch_queries + (uint32_t)lane;
                                         late_row = chunk * late_rows + k_chunk + rank;
                                     }
-                                    e[pkQx * kLot] = __float_as_uint(qx);
-                                    e[pkQy * kLot] = __float_as_uint(qy);
-                                    e[pkQz * kLot] = __float_as_uint(qz);
-                                    e[pkNode * kLot] = (uint32_t)node;
-                                    e[pkPrev * kLot] = (uint32_t)prev;
-                                    e[pkModeSp * kLot] = (uint32_t)mode | (sp << 8);
-                                    e[pkRd * kLot] = __float_as_uint(rd);
-                                    e[pkRid * kLot] = rid;
-                                    e[pkChainM * kLot] = __float_as_uint(chain_m);
-                                    e[pkChainM2 * kLot] = __float_as_uint(chain_m2);
-                                    e[pkArg * kLot] = (uint32_t)arg;
-                                    e[pkRetNode * kLot] = (uint32_t)ret_node;
-                                    e[pkTop * kLot] = (uint32_t)top;
-                                    e[pkNInt * kLot] = n_int;
-                                    e[pkNPts * kLot] = n_pts;
-                                    e[pkOvf * kLot] = ovf;
-                                    e[pkIndex * kLot] = i;
-                                    e[pkRow * kLot] = late_row;
-                                    e[pkStD0 * kLot] = __float_as_uint(st_d[0]);
-                                    e[pkStI0 * kLot] = st_i[0];
-                                    e[pkStD1 * kLot] = __float_as_uint(st_d[kWave]);
-                                    e[pkStI1 * kLot] = st_i[kWave];
+                                    e[pkQx] = __float_as_uint(qx);
+                                    e[pkQy] = __float_as_uint(qy);
+                                    e[pkQz] = __float_as_uint(qz);
+                                    e[pkNode] = (uint32_t)node;
+                                    e[pkPrev] = (uint32_t)prev;
+                                    e[pkModeSp] = (uint32_t)mode | (sp << 8);
+                                    e[pkRd] = __float_as_uint(rd);
+                                    e[pkRid] = rid;
+                                    e[pkChainM] = __float_as_uint(chain_m);
+                                    e[pkChainM2] = __float_as_uint(chain_m2);
+                                    e[pkArg] = (uint32_t)arg;
+                                    e[pkRetNode] = (uint32_t)ret_node;
+                                    e[pkTop] = (uint32_t)top;
+                                    e[pkNInt] = n_int;
+                                    e[pkNPts] = n_pts;
+                                    e[pkOvf] = ovf;
+                                    e[pkIndex] = i;
+                                    e[pkRow] = late_row;
+                                    e[pkStD0] = __float_as_uint(st_d[0]);
+                                    e[pkStI0] = st_i[0];
+                                    e[pkStD1] = __float_as_uint(st_d[kWave]);
+                                    e[pkStI1] = st_i[kWave];
                                     mode = tDone;
                                     valid = false; // not this batch's to finish
                                 }
@@ -1334,7 +1339,7 @@ namespace icp_dev
                         oz = N.cz;
                     }
                     // the query's index: its place in the batch, or what its lot entry says
-                    const uint32_t i = flush ? lot_at(cur ^ 1u, (uint32_t)lane)[pkIndex * kLot]
+                    const uint32_t i = flush ? lot_at(cur ^ 1u, (uint32_t)lane)[pkIndex]
                                              : b * batch_queries + (uint32_t)lane;
                     if (yx)
                     {
@@ -1363,7 +1368,7 @@ namespace icp_dev
                     {
                         // (word by word: built as 16-byte vectors the three counters became
                         // one register tuple for the whole kernel, and that tuple spilled)
-                        const uint32_t late_row = lot_at(cur ^ 1u, (uint32_t)lane)[pkRow * kLot];
+                        const uint32_t late_row = lot_at(cur ^ 1u, (uint32_t)lane)[pkRow];
                         uint32_t* row = cold()->late + (size_t)late_row * kCovSums;
                         row[0] = __float_as_uint(__fmul_rn(qx, ox));
                         row[1] = __float_as_uint(__fmul_rn(qx, oy));
