@@ -49,12 +49,18 @@ namespace icp_dev
     __device__ __forceinline__ float wave_min_nonneg(float v)
     {
         int x = __float_as_int(v);
-        x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x111, 0xf, 0xf, false)); // row_shr:1
-        x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x112, 0xf, 0xf, false)); // row_shr:2
-        x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x114, 0xf, 0xf, false)); // row_shr:4
-        x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x118, 0xf, 0xf, false)); // row_shr:8
-        x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x142, 0xa, 0xf, false)); // row_bcast:15
-        x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x143, 0xc, 0xf, false)); // row_bcast:31
+        // One instruction per step: the minimum with the shifted operand fused into the DPP
+        // form (a lane without a source keeps its value).  Written out because the compiler
+        // makes a copy, a v_mov_dpp and a v_min of each step (18 vector instructions for the six);
+        // s_nop 1: a DPP operand must not be read for two cycles after the VALU wrote it.
+        asm volatile("s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                     "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                     "s_nop 1"
+                     : "+v"(x));
         return __int_as_float(__builtin_amdgcn_readlane(x, 63));
     }
 
