@@ -651,6 +651,8 @@ namespace
             std::fprintf(stderr,
                          "[tile stats] ring walks %llu over %llu lanes, %llu finished by them, %llu wave cycles\n",
                          h[170], h[171], h[172], h[173]);
+            std::fprintf(stderr, "[tile stats] first descent: %llu wave cycles on levels 1-12, %llu below\n",
+                         h[174], h[175]);
             histogram("wave lifetimes", 24, 17);
             histogram("batch durations", 88, 13);
             for (int k = 0; k < 2; ++k)

@@ -573,7 +573,8 @@ namespace icp_dev
                      st_walk_done = 0, st_walk_lanes = 0;
             // shader cycles by phase (diagnostic build only)
             unsigned long long cy_node = 0, cy_tile = 0, cy_coop = 0, cy_exact = 0, cy_tail = 0,
-                               cy_head = 0, cy_total = 0, cy_pop = 0, cy_walk = 0;
+                               cy_head = 0, cy_total = 0, cy_pop = 0, cy_walk = 0, cy_dtop = 0,
+                               cy_dbot = 0, cy_lv = 0;
             const unsigned long long rt_begin = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;
             if (STATS)
                 stats += (size_t)(blockIdx.x % (uint32_t)kTileStatsCopies) * kTileStatsWords;
@@ -818,6 +819,7 @@ namespace icp_dev
                 if (t.root >= 0 && !flush)
                 {
                     uint32_t depth = 0; // wave-uniform: levels gone down
+                    cy_lv = now();
                     for (;;)
                     {
                         const bool going = mode == tDescend;
@@ -826,6 +828,9 @@ namespace icp_dev
                             break;
                         if (STATS)
                         {
+                            const unsigned long long t_lv = now();
+                            (depth < 12u ? cy_dtop : cy_dbot) += t_lv - cy_lv;
+                            cy_lv = t_lv;
                             st_node += 1u;
                             st_node_lanes += (uint32_t)__builtin_popcountll(goers);
                         }
@@ -1498,6 +1503,8 @@ namespace icp_dev
                 atomicAdd(stats + 171, (unsigned long long)st_walk_lanes);
                 atomicAdd(stats + 172, (unsigned long long)st_walk_done);
                 atomicAdd(stats + 173, cy_walk);
+                atomicAdd(stats + 174, cy_dtop);
+                atomicAdd(stats + 175, cy_dbot);
                 atomicMax(stats + 22, cy_total);
                 atomicMax(stats + 23, (unsigned long long)st_batch);
                 // histogram of wave lifetimes (bins of 131072 cycles); first / last wave to start
