@@ -71,7 +71,7 @@ namespace icp_dev
         enum : uint32_t
         {
             pkQx = 0, pkQy, pkQz, pkNode, pkPrev, pkModeSp, pkRd, pkRid, pkChainM, pkChainM2, pkArg,
-            pkRetNode, pkTop, pkNInt, pkNPts, pkOvf, pkIndex, pkRow, pkStD0, pkStI0, pkStD1, pkStI1,
+            pkRetNode, pkFree, pkNInt, pkNPts, pkOvf, pkIndex, pkRow, pkStD0, pkStI0, pkStD1, pkStI1,
             kParkFields,
             kParkWords = 24 // an entry = 96 bytes, its fields side by side: the stores of a lane
                             // that is parked fall into one or two cache lines and merge in L2
@@ -142,6 +142,11 @@ namespace icp_dev
         constexpr int kNearMark = (int)0x80000000; // `prev` of a lane that jumped to the one level
                                                    // of its chain that matters (no child code: there
                                                    // are fewer than 2^31 leaves)
+        constexpr int kFarMark = (int)0x80000001;  // `prev` of a lane that jumped back to the node
+                                                   // its chain hangs from: it arrives from that
+                                                   // node's far side, whichever child that is (the
+                                                   // way up only asks whether `prev` is the near
+                                                   // child; no child code either)
 
         // ---- fixed-order wave sums of doubles without LDS traffic (gfx950 permlane swaps) ----
         // [a | b] : lanes 0..31 get a[l] + a[l+32], lanes 32..63 get b[l-32] + b[l]
@@ -752,9 +757,13 @@ namespace icp_dev
                 // back to `ret_node` (or is done) instead of climbing level by level.
                 // If the answer is below the second smallest only, exactly one level (`arg`) can
                 // matter: the lane goes there, and from there back to `ret_node`.
-                int ret_node = -1, top = t.root, arg = -1;
+                // (A lane that jumps to `ret_node` arrives there from the far side: `prev` =
+                // kFarMark says so; which child that is, the way up does not ask.)
+                int ret_node = -1, arg = -1;
                 float chain_m = __int_as_float(0x7f800000), chain_m2 = chain_m;
-                uint32_t sp = 0, ovf = 0;
+                // stack depth (low 8 bits: a tree is at most 32 levels high) and, above it, how many
+                // entries this query has put into its HBM column (one register instead of two)
+                uint32_t spo = 0;
                 uint32_t n_int = 0, n_pts = 0; // work counters of this query
                 uint32_t low_rounds = 0; // wave-uniform: rounds with no more than park_max lanes at work
                 float rd = 0.f;
@@ -776,17 +785,15 @@ namespace icp_dev
                         prev = (int)e[pkPrev];
                         const uint32_t ms = e[pkModeSp];
                         mode = (int)(ms & 0xFFu);
-                        sp = ms >> 8;
                         rd = __uint_as_float(e[pkRd]);
                         rid = e[pkRid];
                         chain_m = __uint_as_float(e[pkChainM]);
                         chain_m2 = __uint_as_float(e[pkChainM2]);
                         arg = (int)e[pkArg];
                         ret_node = (int)e[pkRetNode];
-                        top = (int)e[pkTop];
                         n_int = e[pkNInt];
                         n_pts = e[pkNPts];
-                        ovf = e[pkOvf];
+                        spo = (ms >> 8) | (e[pkOvf] << 8);
                         st_d[0] = __uint_as_float(e[pkStD0]);
                         st_i[0] = e[pkStI0];
                         st_d[kWave] = __uint_as_float(e[pkStD1]);
@@ -903,7 +910,7 @@ namespace icp_dev
                             // (the queries of a flush have their late rows already)
                             const uint32_t need = flush ? 0u : na;
                             const uint32_t late_rows = cold()->late_rows;
-                            if (__ballot(at_work && sp > (uint32_t)kStackK) == 0ull &&
+                            if (__ballot(at_work && (spo & 0xFFu) > (uint32_t)kStackK) == 0ull &&
                                 k_chunk + need <= late_rows)
                             {
                                 if (at_work)
@@ -928,17 +935,16 @@ namespace icp_dev
                                     e[pkQz] = __float_as_uint(qz);
                                     e[pkNode] = (uint32_t)node;
                                     e[pkPrev] = (uint32_t)prev;
-                                    e[pkModeSp] = (uint32_t)mode | (sp << 8);
+                                    e[pkModeSp] = (uint32_t)mode | ((spo & 0xFFu) << 8);
                                     e[pkRd] = __float_as_uint(rd);
                                     e[pkRid] = rid;
                                     e[pkChainM] = __float_as_uint(chain_m);
                                     e[pkChainM2] = __float_as_uint(chain_m2);
                                     e[pkArg] = (uint32_t)arg;
                                     e[pkRetNode] = (uint32_t)ret_node;
-                                    e[pkTop] = (uint32_t)top;
                                     e[pkNInt] = n_int;
                                     e[pkNPts] = n_pts;
-                                    e[pkOvf] = ovf;
+                                    e[pkOvf] = spo >> 8;
                                     e[pkIndex] = i;
                                     e[pkRow] = late_row;
                                     e[pkStD0] = __float_as_uint(st_d[0]);
@@ -1018,6 +1024,7 @@ namespace icp_dev
                                         const float parked =
                                             (marked && ret_node < 0) ? __uint_as_float(__float_as_uint(rd) | 0x80000000u)
                                                                      : rd;
+                                        const uint32_t sp = spo & 0xFFu;
                                         if (sp < (uint32_t)kStackK)
                                         {
                                             st_d[sp * kWave] = parked;
@@ -1027,20 +1034,20 @@ namespace icp_dev
                                         {
                                             *spill_at(sp - kStackK) =
                                                 make_uint2(__float_as_uint(parked), rid);
-                                            ovf += 1u;
+                                            spo += 0x100u;
                                         }
-                                        sp += 1u;
+                                        spo += 1u;
                                         go = farc; // :160
                                         up = false;
                                         ret_node = node; // a new chain starts at the far child
-                                        top = farc;
                                         chain_m = chain_m2 = __int_as_float(0x7f800000);
                                     }
                                 }
                                 else
                                 {
                                     // back from the far side (:163): far wins only if strictly closer
-                                    sp -= 1u;
+                                    spo -= 1u;
+                                    const uint32_t sp = spo & 0xFFu;
                                     float nd;
                                     uint32_t ni;
                                     if (sp < (uint32_t)kStackK)
@@ -1073,7 +1080,7 @@ namespace icp_dev
                                     }
                                     // nothing between this level and where the chain began can
                                     // change the answer (marked), nor anything above it (done_after)
-                                    prev = marked ? top : node;
+                                    prev = marked ? kFarMark : node;
                                     node = done_after ? -1 : marked ? ret_node : N.parent;
                                     mode = node < 0 ? tDone : tReturn;
                                 }
@@ -1289,7 +1296,7 @@ namespace icp_dev
                             if (r < chain_m)
                             {
                                 node = ret_node;
-                                prev = top;
+                                prev = kFarMark;
                             }
                             else if (r < chain_m2)
                             {
@@ -1306,7 +1313,7 @@ namespace icp_dev
                         if (rd < chain_m)
                         {
                             node = ret_node;
-                            prev = top;
+                            prev = kFarMark;
                         }
                         else if (rd < chain_m2)
                         {
@@ -1386,7 +1393,7 @@ namespace icp_dev
                         row[8] = __float_as_uint(__fmul_rn(qz, oz));
                         row[9] = n_int;
                         row[10] = n_pts;
-                        row[11] = ovf;
+                        row[11] = spo >> 8;
                     }
                 }
                 else
@@ -1394,7 +1401,10 @@ namespace icp_dev
                     // (a lane parked by this batch adds nothing here: ox = oy = oz = 0 and its
                     // counters travel with it)
                     if (!valid)
-                        n_int = n_pts = ovf = 0u;
+                    {
+                        n_int = n_pts = 0u;
+                        spo = 0u;
+                    }
                     double v[kCovSums];
                     v[0] = (double)__fmul_rn(qx, ox);
                     v[1] = (double)__fmul_rn(qx, oy);
@@ -1407,7 +1417,7 @@ namespace icp_dev
                     v[8] = (double)__fmul_rn(qz, oz);
                     v[9] = (double)n_int;
                     v[10] = (double)n_pts;
-                    v[11] = (double)ovf;
+                    v[11] = (double)(spo >> 8);
                     double h[6], r[3];
 #pragma unroll
                     for (int k = 0; k < 6; ++k)
