@@ -208,3 +208,65 @@ def test_noalloc_outputs_are_optional_and_limits_are_enforced(hip):
         with pytest.raises(capi.IcpHipError):
             empty.nn_noalloc(px, py, pz, 10, mu_m)
     hip.release()
+
+
+def _chain_tree(levels: int):
+    """A hand-made tree `levels` edges deep (no build makes one: the reference splits at the median):
+    node i sits at x = 10 i with radius 5, holds one point 1 away inside and everything further out
+    outside.  Returns (struct, arrays kept alive, the points by row)."""
+    from icp_amd import capi
+    nn, nl = levels, levels + 1
+    f32, i32, u32 = np.float32, np.int32, np.uint32
+    keep = dict(
+        node_cx=(10.0 * np.arange(nn)).astype(f32), node_cy=np.zeros(nn, f32), node_cz=np.zeros(nn, f32),
+        node_radius=np.full(nn, 5.0, f32),
+        node_inside=(-1 - np.arange(nn)).astype(i32),                       # leaf i
+        node_outside=np.append(np.arange(1, nn), -1 - nn).astype(i32),      # node i + 1; the last: leaf nn
+        node_parent=(np.arange(nn) - 1).astype(i32), node_row=np.arange(nn).astype(u32),
+        leaf_begin=(16 * np.arange(nl)).astype(u32), leaf_count=np.ones(nl, u32),
+        slot_x=np.full(16 * nl, np.inf, f32), slot_y=np.full(16 * nl, np.inf, f32),
+        slot_z=np.full(16 * nl, np.inf, f32), slot_row=np.full(16 * nl, 0xFFFFFFFF, u32))
+    keep["slot_x"][::16] = np.append(10.0 * np.arange(nn) + 1.0, 10.0 * nn).astype(f32)
+    keep["slot_y"][::16] = 0.0
+    keep["slot_z"][::16] = 0.0
+    keep["slot_row"][::16] = nn + np.arange(nl)
+    s = capi.FlatTreeStruct(n_points=nn + nl, n_slots=16 * nl, n_nodes=nn, n_leaves=nl, height=levels,
+                            capacity=2, max_leaf_count=1, root=0)
+    for name, arr in keep.items():
+        setattr(s, name, arr.ctypes.data_as(type(getattr(s, name))))
+    pts = np.zeros((nn + nl, 3), f32)
+    pts[:nn, 0] = keep["node_cx"]
+    pts[nn:, 0] = keep["slot_x"][::16]
+    return s, keep, pts
+
+
+def test_noalloc_refuses_a_tree_deeper_than_its_static_stack(hip):
+    """Height 33: icp_hip_nn serves it (its overflow stack is allocated by depth, the answers are
+    the brute-force ones), icp_hip_nn_noalloc says ICP_HIP_ERR_DEPTH (2 on-chip entries + 30 in
+    the static array = 32 levels) and names icp_hip_nn."""
+    from icp_amd import capi
+    s, keep, pts = _chain_tree(33)
+    assert capi.load().icp_hip_tree_validate(C.byref(s)) == 0
+    rng = np.random.default_rng(3)
+    q = np.stack([rng.uniform(-5.0, 340.0, 500), rng.normal(0, 2.0, 500), rng.normal(0, 2.0, 500)],
+                 1).astype(np.float32)
+    mu = np.zeros(3, np.float32)
+    with capi.Context() as ctx:
+        ctx.set_tree_struct(s)
+        ctx.set_queries(q)
+        got = ctx.nn(mu)
+        d2 = ((q[:, None, :].astype(np.float64) - pts[None, :, :]) ** 2).sum(2)
+        assert (got["row"] == d2.argmin(1)).all()
+        px, py, pz = (hip.upload(q[:, k]) for k in range(3))
+        row = hip.filled(4 * len(q), 0)
+        with pytest.raises(capi.IcpHipError) as e:
+            ctx.nn_noalloc(px, py, pz, len(q), mu, d_row=row)
+        assert e.value.status == 5 and "32 levels" in str(e.value) and "icp_hip_nn" in str(e.value)
+    s32, keep32, _ = _chain_tree(32)
+    with capi.Context() as ctx:
+        ctx.set_tree_struct(s32)
+        ctx.nn_noalloc(px, py, pz, len(q), mu, d_row=row)  # 32 levels: the limit itself is served
+        hip.sync(0)
+        ctx.set_queries(q)
+        assert (hip.download(row, np.uint32, len(q)) == ctx.nn(mu)["row"]).all()
+    hip.release()
