@@ -253,6 +253,7 @@ namespace
 } // namespace
 
 constexpr uint64_t kParkMinPoints = 6'000'000;       // shards from which the straggler lots pay once aligned
+constexpr uint64_t kParkEarlyMinPoints = 48'000'000; // ... and from which they pay in every pass
 
 struct icp_hip_ctx
 {
@@ -327,13 +328,15 @@ struct icp_hip_ctx
     // When: measured on one MI355X (scripts/park_probe.py, bench.py): once the clouds are aligned
     // the pass is 9-13 % faster from 16M points up, 3 % at 8M, and SLOWER below (every wave ends
     // with a batch of what is left in its lot, which weighs on a short pass); while the clouds
-    // are still a point spacing apart it is 5 % faster at 64M points (best with up to 16 lanes
-    // parked per batch and 8 late rows per batch), even at 32M and 9 % slower at 16M -- and it
-    // fetches 26 GB per 64M pass instead of 9.3: the parked queries of a misaligned batch come
-    // back in batches that stage buckets from all over the tree, each for one lane.  Not worth
-    // it.  So the lots are used on shards of kParkMinPoints and more, in the passes after the
-    // second ordering pass (maybe_resort: the registration's own sign that the clouds are
-    // aligned; +0.8 GB fetched and +0.13 GB written per 64M pass, for 10 % of its time).
+    // are still a point spacing apart it is 6 % faster at 64M points (14.1 -> 13.2 ms; best with
+    // up to 16 lanes parked per batch and 8 late rows per batch), even at 32M and 9 % slower at
+    // 16M -- and it fetches 26 GB per 64M pass instead of 9.3: the parked queries of a
+    // misaligned batch come back in batches that stage buckets from all over the tree, each for
+    // one lane (the fabric has the room: 2 TB/s of 8).  So the lots are used on shards of
+    // kParkMinPoints and more in the passes after the second ordering pass (maybe_resort: the
+    // registration's own sign that the clouds are aligned; +0.8 GB fetched and +0.13 GB
+    // written per 64M pass, for 10 % of its time), and in every pass on shards of
+    // kParkEarlyMinPoints and more (the 64M iteration 4.81 -> 4.69 ms).
     // ICP_HIP_PARK=always / never and ICP_HIP_PARK_MAX / ICP_HIP_LATE_PER_BATCH override (tests,
     // experiments).
     uint32_t park_max_env = 0, late_per_batch_env = 0; // 0: not set
@@ -342,13 +345,14 @@ struct icp_hip_ctx
     bool park_ready = false;      // lots and late rows are allocated for the current launch shape
     bool park_now() const
     {
-        return park_ready && (park_mode == 1 || resorted);
+        return park_ready && (park_mode == 1 || resorted || n_local >= kParkEarlyMinPoints);
     }
     uint32_t park_max() const { return park_max_env ? park_max_env : resorted ? 8u : 16u; }
     uint32_t late_per_batch() const { return late_per_batch_env ? late_per_batch_env : resorted ? 2u : 8u; }
     uint32_t late_per_batch_most() const
     {
-        return late_per_batch_env ? late_per_batch_env : park_mode == 1 ? 8u : 2u;
+        return late_per_batch_env ? late_per_batch_env
+               : park_mode == 1 || n_local >= kParkEarlyMinPoints ? 8u : 2u;
     }
     uint32_t late_rows() const { return late_per_batch() * chunk_batches; }
 
