@@ -328,8 +328,9 @@ struct icp_hip_ctx
     // When: measured on one MI355X (scripts/park_probe.py, bench.py): once the clouds are aligned
     // the pass is 9-13 % faster from 16M points up, 3 % at 8M, and SLOWER below (every wave ends
     // with a batch of what is left in its lot, which weighs on a short pass); while the clouds
-    // are still a point spacing apart it is 6 % faster at 64M points (14.1 -> 13.2 ms; best with
-    // up to 16 lanes parked per batch and 8 late rows per batch), even at 32M and 9 % slower at
+    // are still a point spacing apart it is 6-9 % faster at 64M points (14.0 -> 13.0 ms with up to
+    // 16 lanes parked per batch and 8 late rows per batch, 12.4-12.8 with 12 rows; flat from there
+    // to 24 rows and between 12 and 16 lanes), even at 32M and 9 % slower at
     // 16M -- and it fetches 26 GB per 64M pass instead of 9.3: the parked queries of a
     // misaligned batch come back in batches that stage buckets from all over the tree, each for
     // one lane (the fabric has the room: 2 TB/s of 8).  So the lots are used on shards of
@@ -348,11 +349,11 @@ struct icp_hip_ctx
         return park_ready && (park_mode == 1 || resorted || n_local >= kParkEarlyMinPoints);
     }
     uint32_t park_max() const { return park_max_env ? park_max_env : resorted ? 8u : 16u; }
-    uint32_t late_per_batch() const { return late_per_batch_env ? late_per_batch_env : resorted ? 2u : 8u; }
+    uint32_t late_per_batch() const { return late_per_batch_env ? late_per_batch_env : resorted ? 2u : 12u; }
     uint32_t late_per_batch_most() const
     {
         return late_per_batch_env ? late_per_batch_env
-               : park_mode == 1 || n_local >= kParkEarlyMinPoints ? 8u : 2u;
+               : park_mode == 1 || n_local >= kParkEarlyMinPoints ? 12u : 2u;
     }
     uint32_t late_rows() const { return late_per_batch() * chunk_batches; }
 
