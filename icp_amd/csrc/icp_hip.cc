@@ -253,7 +253,7 @@ namespace
 } // namespace
 
 constexpr uint64_t kParkMinPoints = 6'000'000;       // shards from which the straggler lots pay once aligned
-constexpr uint64_t kParkEarlyMinPoints = 48'000'000; // ... and from which they pay in every pass
+constexpr uint64_t kParkEarlyMinTreePoints = 48'000'000; // reference clouds from which they pay in every pass
 
 struct icp_hip_ctx
 {
@@ -336,8 +336,12 @@ struct icp_hip_ctx
     // one lane (the fabric has the room: 2 TB/s of 8).  So the lots are used on shards of
     // kParkMinPoints and more in the passes after the second ordering pass (maybe_resort: the
     // registration's own sign that the clouds are aligned; +0.8 GB fetched and +0.13 GB
-    // written per 64M pass, for 10 % of its time), and in every pass on shards of
-    // kParkEarlyMinPoints and more (the 64M iteration 4.81 -> 4.69 ms).
+    // written per 64M pass, for 10 % of its time), and in every pass when the REFERENCE cloud
+    // has kParkEarlyMinTreePoints points or more (the 64M iteration 4.81 -> 4.65 ms; a rank's
+    // share of that cloud alike -- scripts/rank_replay.py, misaligned passes of an eighth of it
+    // 1.79 1.74 1.51 1.15 -> 1.58 1.65 1.33 1.01 ms, of a half 7.30 7.01 6.21 4.52 -> 6.81 6.59
+    // 5.75 4.10: what makes the lots pay before the clouds are aligned is a deep tree, in which
+    // a far-side search is long, not a long shard).
     // ICP_HIP_PARK=always / never and ICP_HIP_PARK_MAX / ICP_HIP_LATE_PER_BATCH override (tests,
     // experiments).
     uint32_t park_max_env = 0, late_per_batch_env = 0; // 0: not set
@@ -346,14 +350,14 @@ struct icp_hip_ctx
     bool park_ready = false;      // lots and late rows are allocated for the current launch shape
     bool park_now() const
     {
-        return park_ready && (park_mode == 1 || resorted || n_local >= kParkEarlyMinPoints);
+        return park_ready && (park_mode == 1 || resorted || n_tree_points >= kParkEarlyMinTreePoints);
     }
     uint32_t park_max() const { return park_max_env ? park_max_env : resorted ? 8u : 16u; }
     uint32_t late_per_batch() const { return late_per_batch_env ? late_per_batch_env : resorted ? 2u : 12u; }
     uint32_t late_per_batch_most() const
     {
         return late_per_batch_env ? late_per_batch_env
-               : park_mode == 1 || n_local >= kParkEarlyMinPoints ? 12u : 2u;
+               : park_mode == 1 || n_tree_points >= kParkEarlyMinTreePoints ? 12u : 2u;
     }
     uint32_t late_rows() const { return late_per_batch() * chunk_batches; }
 
